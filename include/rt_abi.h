@@ -1,0 +1,324 @@
+/*
+ * rt_abi.h — C ABI of the MI355X path-tracing backend (librt_amd.so).
+ *
+ * This library is the drop-in for the reference's WGPU compute pass: the
+ * `ComputePipeline` built at /root/reference/src/main.rs:44-54 and dispatched
+ * at /root/reference/src/app.rs:100-101, together with the resources bound to
+ * it (src/main.rs:46-53) and the driver acceleration structure created at
+ * src/scene.rs:56-64.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative RtStatus; rt_last_error()
+ *     returns a thread-local description of the last failure (the Rust side
+ *     maps non-zero to anyhow!(), mirroring src/main.rs:26 `Result<()>`);
+ *   - one context is driven from one host thread (the reference's winit loop,
+ *     src/app.rs:65-103); dispatches are asynchronous on the context's HIP
+ *     stream, like a wgpu queue submit; rt_sync() waits;
+ *   - host arrays are copied at upload time (the reference uploads copies too,
+ *     src/scene.rs:51-52); the library owns BVH memory.
+ *
+ * Byte layouts are WGSL/encase layouts (shaders/types.wgsl:1-57,
+ * src/types.rs:17-90, src/camera.rs:18-26); every offset is static_asserted.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_NO_DEVICE = -2,      /* no HIP device / HIP runtime failure at create */
+    RT_ERR_HIP = -3,            /* a HIP call failed; see rt_last_error() */
+    RT_ERR_NO_SCENE = -4,       /* dispatch before rt_scene_upload */
+    RT_ERR_NO_ACCUM = -5,       /* dispatch before rt_accum_resize / rt_accum_bind */
+    RT_ERR_OUT_OF_MEMORY = -6,
+    RT_ERR_IO = -7,             /* host-side loaders */
+    RT_ERR_PARSE = -8
+} RtStatus;
+
+/* ----------------------------------------------------------------- layouts */
+/* Camera: shaders/types.wgsl:14-21, src/camera.rs:18-26. size 32, align 16. */
+typedef struct RtCamera {
+    float position[3]; /* @0  */
+    float pitch;       /* @12 */
+    float yaw;         /* @16 */
+    float fov;         /* @20 */
+    float aspect;      /* @24 */
+    float _pad;        /* @28 */
+} RtCamera;
+
+/* Uniform: shaders/types.wgsl:1-12, src/types.rs:17-29. size 80. */
+typedef struct RtUniform {
+    uint32_t window[2];          /* @0  */
+    uint32_t _pad0[2];           /* @8  */
+    RtCamera camera;             /* @16 */
+    uint32_t frame;              /* @48 */
+    uint32_t accumulation_frame; /* @52 */
+    uint32_t flags;              /* @56  bit0 = CULL_BACKFACES (src/types.rs:31-35) */
+    float exposure;              /* @60 */
+    float environment;           /* @64  (WGSL spells it `enviroment`) */
+    uint32_t max_bounces;        /* @68 */
+    uint32_t samples;            /* @72 */
+    uint32_t _pad1;              /* @76 */
+} RtUniform;
+
+#define RT_FLAG_CULL_BACKFACES 1u
+
+/* MetalMaterial: shaders/types.wgsl:29-41, src/types.rs:45-58. size 80. */
+typedef struct RtMetalMaterial {
+    float diffuse_color[3];     /* @0  */
+    float _pad0;                /* @12 */
+    float specular_color[3];    /* @16 */
+    float specular_probability; /* @28 */
+    float roughness;            /* @32 */
+    float _pad1[3];             /* @36 */
+    float emission_color[3];    /* @48 */
+    float emission_strength;    /* @60 */
+    uint32_t diffuse_texture;   /* @64  1-based, 0 = none */
+    uint32_t normal_texture;    /* @68  1-based, 0 = none */
+    uint32_t _pad2[2];          /* @72 */
+} RtMetalMaterial;
+
+/* Material: shaders/types.wgsl:23-27, src/types.rs:37-43. size 112. */
+typedef struct RtMaterial {
+    uint32_t tag;               /* @0   0 = metal, 1 = dielectric */
+    uint32_t _pad0[3];          /* @4   */
+    RtMetalMaterial metal;      /* @16  */
+    float refractive_index;     /* @96  DielectricMaterial */
+    uint32_t _pad1[3];          /* @100 */
+} RtMaterial;
+
+/* Model / GpuModel: shaders/types.wgsl:47-51, src/types.rs:65-70. size 128. */
+typedef struct RtGpuModel {
+    RtMaterial material;        /* @0   */
+    uint32_t vertex_start;      /* @112 */
+    uint32_t index_start;       /* @116 */
+    uint32_t _pad[2];           /* @120 */
+} RtGpuModel;
+
+/* Vertex: shaders/types.wgsl:53-57, src/types.rs:85-90. size 48. */
+typedef struct RtVertex {
+    float position[3]; /* @0  */
+    float _pad0;       /* @12 */
+    float normal[3];   /* @16 */
+    float _pad1;       /* @28 */
+    float uv[2];       /* @32 */
+    float _pad2[2];    /* @40 */
+} RtVertex;
+
+/* GeometryPrimitive: src/scene.rs:141-147 (one per OBJ object). size 24. */
+typedef struct RtGeometryPrimitive {
+    uint32_t first_vertex;
+    uint32_t vertex_count;
+    uint32_t first_index;
+    uint32_t index_count;
+    uint64_t transformation_offset; /* index into the 3x4 transform array */
+} RtGeometryPrimitive;
+
+/* Build-defined extension (no counterpart in the reference):
+ * analytic sphere primitive for BASELINE config C4.  size 32. */
+typedef struct RtSphere {
+    float center[3];
+    float radius;
+    uint32_t model;   /* index into models[] for the material */
+    uint32_t _pad[3];
+} RtSphere;
+
+/* Accumulation buffer element: array<vec3f> → stride 16 B, xyz @0
+ * (shaders/main.wgsl:2, src/app.rs:23). */
+#define RT_ACCUM_STRIDE_BYTES 16u
+
+/* Primary-hit AOV element (new, for parity): sample 0 of the
+ * dispatched frame.  geometry_index = OBJ object order, primitive_index =
+ * triangle index inside that object.  Miss = 0xFFFFFFFF in both. */
+typedef struct RtHitId {
+    uint32_t geometry_index;
+    uint32_t primitive_index;
+} RtHitId;
+
+/* Counters since the last rt_stats_reset (device-side, exact). */
+typedef struct RtStats {
+    uint64_t rays;            /* trace_ray calls (shaders/main.wgsl:44) */
+    uint64_t pixel_frames;    /* invocations of `main` that passed the bounds check */
+    uint64_t node_visits;     /* only counted when RT_OPT_COUNT_TRAVERSAL is set */
+    uint64_t triangle_tests;  /* idem */
+    uint64_t dispatches;
+    uint64_t bvh_nodes;       /* static: nodes in the device BVH */
+    uint64_t bvh_bytes;       /* static: bytes of nodes + triangle records on device */
+    double   bvh_build_seconds;
+} RtStats;
+
+/* rt_set_option keys */
+#define RT_OPT_COUNT_TRAVERSAL 1   /* 0/1: count node visits + triangle tests (slower kernel) */
+#define RT_OPT_AOV             2   /* 0/1: write primary hit ids on every dispatch */
+#define RT_OPT_KERNEL          3   /* kernel variant; 0 = default */
+#define RT_OPT_FRONT_FACE_CW   4   /* 0 (default): CCW = front; 1: CW = front */
+
+typedef struct rt_context rt_context;
+
+/* ------------------------------------------------------------- lifecycle */
+/* ≙ Gpu::builder()…build() + compute_pipeline(…).finish(), src/main.rs:27-54 */
+int rt_create(int device_id, rt_context **out);
+int rt_destroy(rt_context *ctx);
+const char *rt_last_error(void);
+/* Use the caller's HIP stream (a hipStream_t) for all device work. NULL = the
+ * library's own stream. */
+int rt_set_stream(rt_context *ctx, void *hip_stream);
+int rt_set_option(rt_context *ctx, int key, int64_t value);
+
+/* ------------------------------------------------------------------ scene */
+/* ≙ Scene::finish, src/scene.rs:50-93: uploads vertex/index/model arrays and
+ * builds the acceleration structure (host SAH BVH build + repack, the part
+ * the Vulkan driver does for the reference at src/scene.rs:56-64).
+ * `transforms` = n_primitives row-major 3x4 matrices, or NULL for identity
+ * (src/scene.rs:53-54). */
+int rt_scene_upload(rt_context *ctx,
+                    const RtVertex *vertices, uint64_t n_vertices,
+                    const uint32_t *indices, uint64_t n_indices,
+                    const RtGeometryPrimitive *primitives, uint32_t n_primitives,
+                    const float *transforms,
+                    const RtGpuModel *models, uint32_t n_models);
+/* Build-defined: adds analytic spheres to the scene (BASELINE config C4).
+ * Must follow rt_scene_upload; rebuilds the acceleration structure. */
+int rt_spheres_upload(rt_context *ctx, const RtSphere *spheres, uint64_t n_spheres);
+/* ≙ App::upload_models, src/app.rs:46-62: re-upload models (materials) and the
+ * per-geometry transforms, then rebuild the acceleration structure
+ * (acceleration_structure.update()).  transforms may be NULL (= unchanged). */
+int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models,
+                     const float *transforms);
+
+/* ----------------------------------------------------------- accumulation */
+/* Row-tile sharding for multi-GPU: the image is cut into bands
+ * of 8 rows (the reference's 8x8 workgroup rows, shaders/main.wgsl:15); band t
+ * belongs to shard t % shard_count.  A context renders only its bands and its
+ * accumulation buffer holds only those rows, packed (band t is local band
+ * t / shard_count).  pixel_idx stays global, so results are bit-identical to
+ * an unsharded render.  Default 0 of 1.  Call before rt_accum_resize/bind. */
+int rt_set_shard(rt_context *ctx, uint32_t shard_index, uint32_t shard_count);
+/* Number of rows / bytes the local accumulation buffer holds for a w x h image. */
+uint64_t rt_accum_local_rows(const rt_context *ctx, uint32_t w, uint32_t h);
+/* ≙ src/app.rs:87-93: (re)allocate a zero-filled accumulation buffer. */
+int rt_accum_resize(rt_context *ctx, uint32_t w, uint32_t h);
+/* Render into caller-owned device memory instead (e.g. a torch tensor that
+ * RCCL will gather).  bytes must be >= local_rows*w*16.  Not zeroed. */
+int rt_accum_bind(rt_context *ctx, void *device_ptr, uint64_t bytes, uint32_t w, uint32_t h);
+
+/* --------------------------------------------------------------- dispatch */
+/* ≙ uniform_buffer.upload + compute_pipeline.dispatch(ceil(W/8), ceil(H/8), 1),
+ * src/app.rs:95-101.  uniform->window must equal the accumulation size. */
+int rt_dispatch(rt_context *ctx, const RtUniform *uniform);
+/* n_frames consecutive dispatches; before each one `frame` is bumped and
+ * `accumulation_frame` follows the cold-start sequence of src/app.rs:78-96
+ * (first dispatch after a resize sees accumulation_frame = 0).  On return
+ * *uniform holds the values of the last dispatch. */
+int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames);
+int rt_sync(rt_context *ctx);
+
+/* ---------------------------------------------------------------- readback */
+/* ≙ accumulation_buffer.download_async, src/ui.rs:82.  dst receives
+ * local_rows*w elements of 16 B (xyz + pad).  Synchronises. */
+int rt_accum_download(rt_context *ctx, float *dst);
+/* local_rows*w RtHitId elements; requires RT_OPT_AOV=1 before the dispatch. */
+int rt_aov_download(rt_context *ctx, RtHitId *dst);
+int rt_stats(rt_context *ctx, RtStats *out);
+int rt_stats_reset(rt_context *ctx);
+/* Device time of the last rt_dispatch/rt_dispatch_frames call in milliseconds,
+ * measured with HIP events on the context's stream.  Synchronises. */
+int rt_last_dispatch_ms(rt_context *ctx, float *ms);
+
+/* ------------------------------------------------- host side (no GPU use) */
+/* Host mirror of the reference's Rust host for this path.  These run on the
+ * CPU only and are what the Rust host keeps doing in the reference. */
+
+/* ≙ Scene::load, src/scene.rs:95-207 (+ tobj 4.0.3 triangulate/single_index
+ * semantics, src/misc.rs:49-75 for Pm/Pr/Ke). */
+typedef struct rt_host_scene rt_host_scene;
+int rt_host_scene_load(const char *obj_path, rt_host_scene **out);
+void rt_host_scene_free(rt_host_scene *s);
+uint64_t rt_host_scene_vertex_count(const rt_host_scene *s);
+uint64_t rt_host_scene_index_count(const rt_host_scene *s);
+uint32_t rt_host_scene_model_count(const rt_host_scene *s);
+const RtVertex *rt_host_scene_vertices(const rt_host_scene *s);
+const uint32_t *rt_host_scene_indices(const rt_host_scene *s);
+const RtGeometryPrimitive *rt_host_scene_primitives(const rt_host_scene *s);
+const RtGpuModel *rt_host_scene_models(const rt_host_scene *s);
+const char *rt_host_scene_model_name(const rt_host_scene *s, uint32_t i);
+/* ≙ scene.finish(&gpu), src/main.rs:39 */
+int rt_host_scene_finish(const rt_host_scene *s, rt_context *ctx);
+
+/* ≙ the Uniform literal at src/main.rs:73-84 + Camera::default,
+ * src/camera.rs:112-123 */
+void rt_host_uniform_default(RtUniform *u);
+
+/* Capture ≙ src/ui.rs:82-93: (x*255) as u8 per channel (truncating,
+ * saturating), RGB8.  src = n_pixels 16-B elements; dst = n_pixels*3 bytes. */
+void rt_host_capture_rgb8(const float *src, uint64_t n_pixels, uint8_t *dst);
+/* Writes an RGB8 PNG (stored/uncompressed deflate). */
+int rt_host_write_png(const char *path, const uint8_t *rgb, uint32_t w, uint32_t h);
+
+/* BVH build exposed for CPU-side inspection/tests: builds the same tree
+ * rt_scene_upload builds and reports its shape. */
+typedef struct RtBvhInfo {
+    uint64_t n_triangles;
+    uint64_t n_nodes;
+    uint64_t n_leaves;
+    uint32_t max_depth;
+    uint32_t max_leaf_size;
+    double   sah_cost;
+    double   build_seconds;
+} RtBvhInfo;
+int rt_host_bvh_info(const RtVertex *vertices, uint64_t n_vertices,
+                     const uint32_t *indices, uint64_t n_indices,
+                     const RtGeometryPrimitive *primitives, uint32_t n_primitives,
+                     const float *transforms, RtBvhInfo *out);
+
+#ifdef __cplusplus
+} /* extern "C" */
+
+#define RT_LAYOUT_ASSERT(T, field, off) \
+    static_assert(offsetof(T, field) == (off), #T "." #field " offset")
+static_assert(sizeof(RtCamera) == 32, "Camera size");
+RT_LAYOUT_ASSERT(RtCamera, pitch, 12);
+RT_LAYOUT_ASSERT(RtCamera, yaw, 16);
+RT_LAYOUT_ASSERT(RtCamera, fov, 20);
+RT_LAYOUT_ASSERT(RtCamera, aspect, 24);
+static_assert(sizeof(RtUniform) == 80, "Uniform size");
+RT_LAYOUT_ASSERT(RtUniform, camera, 16);
+RT_LAYOUT_ASSERT(RtUniform, frame, 48);
+RT_LAYOUT_ASSERT(RtUniform, accumulation_frame, 52);
+RT_LAYOUT_ASSERT(RtUniform, flags, 56);
+RT_LAYOUT_ASSERT(RtUniform, exposure, 60);
+RT_LAYOUT_ASSERT(RtUniform, environment, 64);
+RT_LAYOUT_ASSERT(RtUniform, max_bounces, 68);
+RT_LAYOUT_ASSERT(RtUniform, samples, 72);
+static_assert(sizeof(RtMetalMaterial) == 80, "MetalMaterial size");
+RT_LAYOUT_ASSERT(RtMetalMaterial, specular_color, 16);
+RT_LAYOUT_ASSERT(RtMetalMaterial, specular_probability, 28);
+RT_LAYOUT_ASSERT(RtMetalMaterial, roughness, 32);
+RT_LAYOUT_ASSERT(RtMetalMaterial, emission_color, 48);
+RT_LAYOUT_ASSERT(RtMetalMaterial, emission_strength, 60);
+RT_LAYOUT_ASSERT(RtMetalMaterial, diffuse_texture, 64);
+RT_LAYOUT_ASSERT(RtMetalMaterial, normal_texture, 68);
+static_assert(sizeof(RtMaterial) == 112, "Material size");
+RT_LAYOUT_ASSERT(RtMaterial, metal, 16);
+RT_LAYOUT_ASSERT(RtMaterial, refractive_index, 96);
+static_assert(sizeof(RtGpuModel) == 128, "GpuModel size");
+RT_LAYOUT_ASSERT(RtGpuModel, vertex_start, 112);
+RT_LAYOUT_ASSERT(RtGpuModel, index_start, 116);
+static_assert(sizeof(RtVertex) == 48, "Vertex size");
+RT_LAYOUT_ASSERT(RtVertex, normal, 16);
+RT_LAYOUT_ASSERT(RtVertex, uv, 32);
+static_assert(sizeof(RtGeometryPrimitive) == 24, "GeometryPrimitive size");
+static_assert(sizeof(RtSphere) == 32, "Sphere size");
+static_assert(sizeof(RtHitId) == 8, "HitId size");
+#undef RT_LAYOUT_ASSERT
+#endif /* __cplusplus */
+
+#endif /* RT_ABI_H */

@@ -1,0 +1,729 @@
+/*
+ * rt_oracle.c — CPU restatement of the reference's WGPU compute pass.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ray-tracing_amd/ may include, link
+ * or call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, as the checker.
+ *
+ * PARITY UNPINNED against the running reference: the reference (Rust + WGSL +
+ * a Vulkan ray-query driver) cannot be built or run here, and it ships no
+ * tests, golden images or known-answer vectors.  What pins
+ * this file: the RNG known-answer vectors derivable from the WGSL constants
+ * (tests/golden/rng_kat.json), the WGSL/encase byte layouts, and the closed
+ * -form ray count of the closed cornell box.
+ *
+ * Each function cites the reference lines it follows.  Arithmetic contract
+ * ("RTN-1"): IEEE binary32, round-to-nearest-even, no FMA
+ * contraction (-ffp-contract=off) except the explicit fmaf() calls in the
+ * ray/triangle and ray/sphere tests; division and sqrt correctly rounded;
+ * sin/cos by the polynomial below (WGSL leaves their accuracy to the driver,
+ * so the contract fixes one implementation); pow(x,5) by three multiplies.
+ * The acceleration structure itself is the Vulkan driver's in the reference
+ * (shaders/main.wgsl:79-83) and has no reference code: the ground truth here
+ * is brute force over all triangles; a SAH BVH2 gives the same hits faster
+ * and counts node visits / triangle tests for the byte model.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+/* ------------------------------------------------------------ layouts ---- */
+/* restated from shaders/types.wgsl:1-57 + WGSL alignment rules; deliberately
+ * NOT taken from include/rt_abi.h so that a layout slip there is caught. */
+typedef struct { float pos[3]; float pitch, yaw, fov, aspect, _pad; } OCamera;   /* types.wgsl:14-21 */
+typedef struct {
+    uint32_t window[2], _pad0[2];
+    OCamera camera;
+    uint32_t frame, accumulation_frame, flags;
+    float exposure, enviroment;
+    uint32_t max_bounces, samples, _pad1;
+} OUniform;                                                                      /* types.wgsl:1-12 */
+typedef struct {
+    float diffuse_color[3], _p0;
+    float specular_color[3];
+    float specular_probability, roughness, _p1[3];
+    float emission_color[3];
+    float emission_strength;
+    uint32_t diffuse_texture, normal_texture, _p2[2];
+} OMetal;                                                                        /* types.wgsl:29-41 */
+typedef struct { uint32_t tag, _p0[3]; OMetal metal; float refractive_index; uint32_t _p1[3]; } OMaterial; /* :23-27 */
+typedef struct { OMaterial material; uint32_t vertex_start, index_start, _p[2]; } OModel;                /* :47-51 */
+typedef struct { float position[3], _p0, normal[3], _p1, uv[2], _p2[2]; } OVertex;                       /* :53-57 */
+typedef struct { uint32_t first_vertex, vertex_count, first_index, index_count; uint64_t transformation_offset; } OPrimitive; /* src/scene.rs:141-147 */
+typedef struct { float center[3], radius; uint32_t model, _p[3]; } OSphere;     /* build-defined, SURVEY §8 A5 */
+
+_Static_assert(sizeof(OCamera) == 32, "Camera");
+_Static_assert(sizeof(OUniform) == 80, "Uniform");
+_Static_assert(sizeof(OMetal) == 80, "MetalMaterial");
+_Static_assert(sizeof(OMaterial) == 112, "Material");
+_Static_assert(sizeof(OModel) == 128, "Model");
+_Static_assert(sizeof(OVertex) == 48, "Vertex");
+_Static_assert(sizeof(OPrimitive) == 24, "GeometryPrimitive");
+
+typedef struct { float x, y, z; } v3;
+
+/* the intersectable form of one triangle: the three (geometry-transformed)
+ * corner positions, in the order of the index buffer */
+typedef struct { v3 a, b, c; uint32_t geometry, primitive; } OTri;
+
+typedef struct {
+    float lo[3], hi[3];
+    uint32_t left;   /* inner: index of left child, right = left+1; leaf: first triangle slot */
+    uint32_t count;  /* 0 = inner; >0 = leaf with `count` triangles */
+} ONode;
+
+typedef struct {
+    const OVertex *vertices;
+    const uint32_t *indices;
+    const OModel *models;
+    const OSphere *spheres;
+    uint64_t n_spheres;
+    OTri *tris;          /* in global triangle order (index buffer order) */
+    uint64_t n_tris;
+    uint32_t *order;     /* BVH leaf order → global triangle id */
+    ONode *nodes;
+    uint64_t n_nodes;
+    int front_face_cw;
+} OScene;
+
+typedef struct {
+    uint64_t rays, node_visits, triangle_tests, hits, pixel_frames;
+} OCounters;
+
+/* --------------------------------------------------------- vector helpers */
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 scale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 cross(v3 a, v3 b) {
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* WGSL normalize(v) = v / length(v); RTN-1: one reciprocal, three multiplies */
+static inline v3 normalize(v3 a) {
+    float inv = 1.0f / sqrtf(dot(a, a));
+    return scale(a, inv);
+}
+/* WGSL mix(a, b, t) = a*(1-t) + b*t */
+static inline v3 mix3(v3 a, v3 b, float t) { return add(scale(a, 1.0f - t), scale(b, t)); }
+/* WGSL reflect(e1, e2) = e1 - 2*dot(e2, e1)*e2 */
+static inline v3 reflect(v3 e1, v3 e2) { return sub(e1, scale(e2, 2.0f * dot(e2, e1))); }
+/* WGSL refract(e1, e2, e3) */
+static inline v3 refract(v3 e1, v3 e2, float e3) {
+    float d = dot(e2, e1);
+    float k = 1.0f - e3 * e3 * (1.0f - d * d);
+    if (k < 0.0f) return V(0.0f, 0.0f, 0.0f);
+    return sub(scale(e1, e3), scale(e2, e3 * d + sqrtf(k)));
+}
+/* WGSL faceForward(e1, e2, e3) = dot(e2, e3) < 0 ? e1 : -e1 */
+static inline v3 face_forward(v3 e1, v3 e2, v3 e3) { return dot(e2, e3) < 0.0f ? e1 : neg(e1); }
+
+/* ------------------------------------------------------ RTN-1 sin / cos -- */
+/* Quadrant reduction by a three-part pi/2 (Cody-Waite, with fmaf) and the
+ * classic single-precision minimax polynomials on [-pi/4, pi/4].  Accurate to
+ * about 1 ulp for |x| < 1e4, far inside Vulkan's 2^-11 absolute allowance. */
+void oracle_sincos(float x, float *s_out, float *c_out) {
+    float kf = floorf(x * 0.63661977236758134308f + 0.5f);
+    float r = fmaf(kf, -1.5703125f, x);
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.54978995489188216e-8f, r);
+    float z = r * r;
+    float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
+               - 0.5f * z + 1.0f;
+    int q = (int)kf & 3;
+    float s = (q & 1) ? cp : sp;
+    float c = (q & 1) ? sp : cp;
+    if (q & 2) s = -s;
+    if ((q + 1) & 2) c = -c;
+    *s_out = s;
+    *c_out = c;
+}
+static inline float o_sin(float x) { float s, c; oracle_sincos(x, &s, &c); return s; }
+static inline float o_cos(float x) { float s, c; oracle_sincos(x, &s, &c); return c; }
+static inline float o_tan(float x) { float s, c; oracle_sincos(x, &s, &c); return s / c; }
+
+/* ------------------------------------------------------------------ RNG -- */
+/* shaders/random.wgsl:1-7 */
+float oracle_rand(uint32_t *seed) {
+    *seed = *seed * 747796405u + 2891336453u;
+    float f = (float)(*seed >> 9) / (float)(1u << 23);
+    return f - floorf(f); /* fract */
+}
+/* shaders/main.wgsl:23 */
+uint32_t oracle_seed(uint32_t pixel_idx, uint32_t frame) {
+    return (pixel_idx * 2479898233u) ^ (frame * 98379842u);
+}
+
+/* ----------------------------------------------------------- misc.wgsl --- */
+/* shaders/misc.wgsl:1-4 */
+static v3 background_color(v3 dir) {
+    float a = 0.5f * (dir.y + 1.0f);
+    float w = 1.0f - a;
+    return V(w * 1.0f + a * 0.5f, w * 1.0f + a * 0.7f, w * 1.0f + a * 1.0f);
+}
+/* shaders/misc.wgsl:10-18 */
+static v3 tangent_space(v3 normal, v3 s) {
+    v3 arbitrary = V(1.0f, 0.0f, 0.0f);
+    if (fabsf(normal.x) > 0.9f) arbitrary = V(0.0f, 1.0f, 0.0f);
+    else if (fabsf(normal.y) > 0.9f) arbitrary = V(0.0f, 0.0f, 1.0f);
+    v3 tangent = normalize(cross(arbitrary, normal));
+    v3 bitangent = cross(normal, tangent);
+    return add(add(scale(tangent, s.x), scale(bitangent, s.y)), scale(normal, s.z));
+}
+/* shaders/random.wgsl:18-29; PI from shaders/main.wgsl:12 */
+static v3 rand_cosine_hemisphere_vector(uint32_t *seed, v3 normal) {
+    const float PI = 3.141592653589793f;
+    float r = sqrtf(oracle_rand(seed));
+    float theta = 2.0f * PI * oracle_rand(seed);
+    float st, ct;
+    oracle_sincos(theta, &st, &ct);
+    v3 s = V(r * ct, r * st, sqrtf(1.0f - r * r));
+    return tangent_space(normal, s);
+}
+
+/* ------------------------------------------------------------ ray.wgsl --- */
+/* shaders/ray.wgsl:51-60 */
+static v3 camera_direction(const OCamera *cam) {
+    float sy, cy, sp, cp;
+    oracle_sincos(cam->yaw, &sy, &cy);
+    oracle_sincos(cam->pitch, &sp, &cp);
+    return normalize(V(cy * cp, sp, sy * cp));
+}
+/* shaders/ray.wgsl:1-10 */
+static v3 ray_direction(const OCamera *cam, float px, float py) {
+    v3 forward = camera_direction(cam);
+    v3 right = normalize(cross(V(0.0f, 1.0f, 0.0f), forward));
+    v3 up = normalize(cross(forward, right));
+    float fov_scale = o_tan(cam->fov * 0.5f);
+    float ux = px * cam->aspect * fov_scale;
+    float uy = py * 1.0f * fov_scale;
+    return normalize(add(add(forward, scale(right, ux)), scale(up, uy)));
+}
+
+typedef struct {
+    int hit, front_face;
+    const OMaterial *material;
+    v3 normal, position;
+    float uv[2];
+    uint32_t geometry, primitive;
+} OIntersection;
+
+typedef struct { v3 direction, color; } OScatter;
+
+/* shaders/ray.wgsl:12-32.  Texture paths (normal_texture / diffuse_texture
+ * > 0) are SURVEY §8 N3, not exercised by any scene here: ids are ignored. */
+static OScatter scattered_direction_metal(uint32_t *seed, v3 dir, const OIntersection *tr, const OMetal *m) {
+    float is_specular = (oracle_rand(seed) < m->specular_probability) ? 1.0f : 0.0f;
+    float smoothness = 1.0f - m->roughness;
+    v3 normal = tr->normal;
+    v3 diffuse = rand_cosine_hemisphere_vector(seed, normal);
+    v3 specular = reflect(dir, normal);
+    v3 diffuse_color = V(m->diffuse_color[0], m->diffuse_color[1], m->diffuse_color[2]);
+    v3 specular_color = V(m->specular_color[0], m->specular_color[1], m->specular_color[2]);
+    OScatter r;
+    r.direction = mix3(diffuse, specular, smoothness * is_specular);
+    r.color = mix3(diffuse_color, specular_color, is_specular);
+    return r;
+}
+/* shaders/main.wgsl:104-108; pow(x, 5.0) = ((x*x)*(x*x))*x under RTN-1 */
+static float schlick_approximation(float cos_theta, float refractive_index) {
+    float r = (1.0f - refractive_index) / (1.0f + refractive_index);
+    float rs = r * r;
+    float x = 1.0f - cos_theta;
+    float x2 = x * x;
+    float x5 = (x2 * x2) * x;
+    return rs + (1.0f - rs) * x5;
+}
+/* shaders/ray.wgsl:34-49 */
+static v3 scattered_direction_dielectric(uint32_t *seed, v3 dir, const OIntersection *tr, float material_ri) {
+    v3 normal = face_forward(tr->normal, tr->normal, dir);
+    float ri = material_ri;
+    if (tr->front_face) ri = 1.0f / material_ri;
+    float c = dot(neg(dir), normal);
+    float cos_theta = (c < 1.0f) ? c : 1.0f; /* min(c, 1.0) */
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    int must_reflect = ri * sin_theta > 1.0f;
+    float reflect_prob = schlick_approximation(cos_theta, ri);
+    /* WGSL || short-circuits: no draw when must_reflect (ray.wgsl:45) */
+    int refl = must_reflect || (reflect_prob > oracle_rand(seed));
+    if (refl) return reflect(dir, normal);
+    return refract(dir, normal, ri);
+}
+
+/* ------------------------------------------- the acceleration structure --- */
+/* Ray/triangle test of the contract (Moller-Trumbore with explicit fmaf).
+ * Replaces the driver's test behind rayQueryProceed (shaders/main.wgsl:81).
+ * Returns 1 and (t,u,v,det) when origin + t*dir lies in the triangle. */
+static inline float dot_fma(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+static inline v3 cross_fma(v3 a, v3 b) {
+    return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline int tri_test(const OTri *tr, v3 o, v3 d, float *t, float *u, float *v, float *det_out) {
+    v3 e1 = sub(tr->b, tr->a), e2 = sub(tr->c, tr->a);
+    v3 p = cross_fma(d, e2);
+    float det = dot_fma(e1, p);
+    if (!(det > 0.0f || det < 0.0f)) return 0;
+    float inv = 1.0f / det;
+    v3 tv = sub(o, tr->a);
+    float uu = dot_fma(tv, p) * inv;
+    if (!(uu >= 0.0f && uu <= 1.0f)) return 0;
+    v3 q = cross_fma(tv, e1);
+    float vv = dot_fma(d, q) * inv;
+    if (!(vv >= 0.0f && uu + vv <= 1.0f)) return 0;
+    *t = dot_fma(e2, q) * inv;
+    *u = uu; *v = vv; *det_out = det;
+    return 1;
+}
+/* Ray/sphere (build-defined): nearest root in (tmin, tbest). */
+static inline int sphere_test(const OSphere *s, v3 o, v3 d, float tmin, float tbest, float *t) {
+    v3 oc = sub(o, V(s->center[0], s->center[1], s->center[2]));
+    float a = dot_fma(d, d);
+    float hb = dot_fma(oc, d);
+    float c = fmaf(-s->radius, s->radius, dot_fma(oc, oc));
+    float disc = fmaf(hb, hb, -(a * c));
+    if (!(disc >= 0.0f)) return 0;
+    float sq = sqrtf(disc);
+    float t0 = (-hb - sq) / a;
+    if (t0 > tmin && t0 < tbest) { *t = t0; return 1; }
+    float t1 = (-hb + sq) / a;
+    if (t1 > tmin && t1 < tbest) { *t = t1; return 1; }
+    return 0;
+}
+
+typedef struct {
+    float t, u, v;
+    uint32_t id;        /* global triangle id, or n_tris + sphere id */
+    int front;
+} OHit;
+
+#define O_NO_HIT 0xFFFFFFFFu
+
+/* committed-hit rule of the contract: nearest t in (tmin, tmax); equal t →
+ * lower global id.  cull = RayDesc flag 0x10 (cull back-facing), main.wgsl:76 */
+static inline void consider_tri(const OScene *sc, uint32_t id, v3 o, v3 d, float tmin, int cull, OHit *best) {
+    float t, u, v, det;
+    if (!tri_test(&sc->tris[id], o, d, &t, &u, &v, &det)) return;
+    int front = sc->front_face_cw ? (det < 0.0f) : (det > 0.0f);
+    if (cull && !front) return;
+    if (!(t > tmin)) return;
+    if (t < best->t || (t == best->t && id < best->id)) {
+        best->t = t; best->u = u; best->v = v; best->id = id; best->front = front;
+    }
+}
+static inline void consider_sphere(const OScene *sc, uint64_t si, v3 o, v3 d, float tmin, OHit *best) {
+    float t;
+    uint32_t id = (uint32_t)(sc->n_tris + si);
+    /* strict t < best, or equal t with lower id */
+    if (!sphere_test(&sc->spheres[si], o, d, tmin, INFINITY, &t)) return;
+    if (t < best->t || (t == best->t && id < best->id)) {
+        best->t = t; best->u = 0.0f; best->v = 0.0f; best->id = id; best->front = -1;
+    }
+}
+
+static void nearest_brute(const OScene *sc, v3 o, v3 d, float tmin, float tmax, int cull, OHit *best, OCounters *cnt) {
+    best->t = tmax; best->id = O_NO_HIT;
+    for (uint64_t i = 0; i < sc->n_tris; i++) consider_tri(sc, (uint32_t)i, o, d, tmin, cull, best);
+    for (uint64_t i = 0; i < sc->n_spheres; i++) consider_sphere(sc, i, o, d, tmin, best);
+    cnt->triangle_tests += sc->n_tris;
+}
+
+/* slab test, conservative: far side widened by a few ulp (Ize 2013) */
+static inline int box_test(const ONode *n, v3 o, v3 inv, float tmin, float tbest, float *tnear) {
+    float tx0 = (n->lo[0] - o.x) * inv.x, tx1 = (n->hi[0] - o.x) * inv.x;
+    float ty0 = (n->lo[1] - o.y) * inv.y, ty1 = (n->hi[1] - o.y) * inv.y;
+    float tz0 = (n->lo[2] - o.z) * inv.z, tz1 = (n->hi[2] - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tmin));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
+    *tnear = tn;
+    return tn <= tf * 1.0000004f;
+}
+
+static void nearest_bvh(const OScene *sc, v3 o, v3 d, float tmin, float tmax, int cull, OHit *best, OCounters *cnt) {
+    best->t = tmax; best->id = O_NO_HIT;
+    /* spheres are not in the oracle's BVH: test them all (small counts only) */
+    for (uint64_t i = 0; i < sc->n_spheres; i++) consider_sphere(sc, i, o, d, tmin, best);
+    if (sc->n_nodes == 0) return;
+    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    uint32_t stack[128];
+    int sp = 0;
+    float tn;
+    cnt->node_visits++;
+    if (!box_test(&sc->nodes[0], o, inv, tmin, best->t, &tn)) return;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const ONode *n = &sc->nodes[stack[--sp]];
+        if (n->count) {
+            for (uint32_t i = 0; i < n->count; i++) {
+                cnt->triangle_tests++;
+                consider_tri(sc, sc->order[n->left + i], o, d, tmin, cull, best);
+            }
+            continue;
+        }
+        float t0, t1;
+        cnt->node_visits += 2;
+        int h0 = box_test(&sc->nodes[n->left], o, inv, tmin, best->t, &t0);
+        int h1 = box_test(&sc->nodes[n->left + 1], o, inv, tmin, best->t, &t1);
+        if (h0 && h1) {
+            uint32_t nearc = n->left, farc = n->left + 1;
+            if (t1 < t0) { nearc = n->left + 1; farc = n->left; }
+            stack[sp++] = farc;
+            stack[sp++] = nearc;
+        } else if (h0) stack[sp++] = n->left;
+        else if (h1) stack[sp++] = n->left + 1;
+    }
+}
+
+/* shaders/main.wgsl:75-102 */
+static OIntersection trace_ray(const OScene *sc, const OUniform *ctx, v3 o, v3 d, int mode, OCounters *cnt) {
+    int cull = (ctx->flags & 1u) != 0;            /* flags = 0x10 * (ctx.flags & 1) */
+    const float tmin = 0.001f, tmax = 3.40282347e+38f;
+    OHit h;
+    cnt->rays++;
+    if (mode == 0) nearest_brute(sc, o, d, tmin, tmax, cull, &h, cnt);
+    else nearest_bvh(sc, o, d, tmin, tmax, cull, &h, cnt);
+
+    OIntersection r;
+    memset(&r, 0, sizeof r);
+    if (h.id == O_NO_HIT) { /* intersection_miss(), shaders/types.wgsl:78-80 */
+        r.hit = 0; r.front_face = 1; r.geometry = O_NO_HIT; r.primitive = O_NO_HIT;
+        return r;
+    }
+    cnt->hits++;
+    r.hit = 1;
+    if (h.id >= sc->n_tris) { /* sphere: normal (P-C)/r, uv 0 */
+        const OSphere *s = &sc->spheres[h.id - sc->n_tris];
+        v3 p = add(o, scale(d, h.t));
+        v3 n = scale(sub(p, V(s->center[0], s->center[1], s->center[2])), 1.0f / s->radius);
+        r.front_face = dot(d, n) < 0.0f;
+        r.material = &sc->models[s->model].material;
+        r.normal = n; r.position = p;
+        r.geometry = 0x80000000u | (uint32_t)(h.id - sc->n_tris); r.primitive = 0;
+        return r;
+    }
+    const OTri *tr = &sc->tris[h.id];
+    const OModel *model = &sc->models[tr->geometry];                    /* main.wgsl:86 */
+    uint32_t index_start = model->index_start + tr->primitive * 3u;     /* :87 */
+    const OVertex *v0 = &sc->vertices[model->vertex_start + sc->indices[index_start]];     /* :89 */
+    const OVertex *v1 = &sc->vertices[model->vertex_start + sc->indices[index_start + 1]]; /* :90 */
+    const OVertex *v2 = &sc->vertices[model->vertex_start + sc->indices[index_start + 2]]; /* :91 */
+    float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;                    /* :93 */
+    for (int k = 0; k < 3; k++) {
+        (&r.normal.x)[k] = v0->normal[k] * b0 + v1->normal[k] * b1 + v2->normal[k] * b2;       /* :94 */
+        (&r.position.x)[k] = v0->position[k] * b0 + v1->position[k] * b1 + v2->position[k] * b2; /* :95 */
+    }
+    r.uv[0] = v0->uv[0] * b0 + v1->uv[0] * b1 + v2->uv[0] * b2;         /* :96 */
+    r.uv[1] = v0->uv[1] * b0 + v1->uv[1] * b1 + v2->uv[1] * b2;
+    /* object_to_world is the instance transform = identity (src/scene.rs:61) */
+    r.front_face = h.front;
+    r.material = &model->material;
+    r.geometry = tr->geometry; r.primitive = tr->primitive;
+    return r;
+}
+
+/* shaders/main.wgsl:35-72 */
+static v3 sample_path(const OScene *sc, const OUniform *ctx, uint32_t *seed, float px, float py,
+                      int mode, OCounters *cnt, uint32_t *first_hit /* [2] or NULL */) {
+    float r0 = oracle_rand(seed), r1 = oracle_rand(seed);
+    float offx = (r0 * 2.0f - 1.0f) / (float)ctx->window[0];
+    float offy = (r1 * 2.0f - 1.0f) / (float)ctx->window[1];
+    v3 dir = ray_direction(&ctx->camera, px + offx, py + offy);
+    v3 pos = V(ctx->camera.pos[0], ctx->camera.pos[1], ctx->camera.pos[2]);
+
+    v3 light = V(0.0f, 0.0f, 0.0f);
+    v3 color = V(1.0f, 1.0f, 1.0f);
+
+    for (uint32_t bounce = 0; bounce <= ctx->max_bounces; bounce++) {
+        OIntersection tr = trace_ray(sc, ctx, pos, dir, mode, cnt);
+        if (bounce == 0 && first_hit) { first_hit[0] = tr.geometry; first_hit[1] = tr.primitive; }
+        if (!tr.hit) {
+            light = add(light, scale(mul(background_color(dir), color), ctx->enviroment));
+            break;
+        }
+        if (tr.material->tag == 0) {
+            const OMetal *m = &tr.material->metal;
+            v3 emitted = scale(V(m->emission_color[0], m->emission_color[1], m->emission_color[2]), m->emission_strength);
+            OScatter sc2 = scattered_direction_metal(seed, dir, &tr, m);
+            light = add(light, mul(emitted, color));
+            color = mul(color, sc2.color);
+            pos = add(tr.position, scale(tr.normal, 0.0001f));
+            dir = sc2.direction;
+        } else if (tr.material->tag == 1) {
+            v3 next_dir = scattered_direction_dielectric(seed, dir, &tr, tr.material->refractive_index);
+            v3 offset_dir = sub(tr.normal, scale(scale(tr.normal, 2.0f), (float)tr.front_face));
+            pos = add(tr.position, scale(offset_dir, 0.0001f));
+            dir = next_dir;
+        }
+    }
+    return light;
+}
+
+/* shaders/main.wgsl:111-118 */
+static v3 tone_map(v3 x) {
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    v3 r;
+    for (int k = 0; k < 3; k++) {
+        float xv = (&x.x)[k];
+        float q = (xv * (a * xv + b)) / (xv * (c * xv + d) + e);
+        q = (q > 0.0f) ? q : 0.0f;   /* saturate; NaN -> 0 */
+        q = (q < 1.0f) ? q : 1.0f;
+        (&r.x)[k] = q;
+    }
+    return r;
+}
+
+/* shaders/main.wgsl:14-33 for rows [y0, y1).  accum = W*H elements of 4 f32
+ * (16-B stride, xyz @0); hit_ids = W*H*2 u32 or NULL (primary hit of sample 0).
+ * mode 0 = brute force, 1 = BVH. */
+void oracle_render_rows(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids,
+                        uint32_t y0, uint32_t y1, int mode, OCounters *counters) {
+    uint32_t W = ctx->window[0], H = ctx->window[1];
+    if (y1 > H) y1 = H;
+    OCounters total;
+    memset(&total, 0, sizeof total);
+#pragma omp parallel
+    {
+        OCounters cnt;
+        memset(&cnt, 0, sizeof cnt);
+#pragma omp for schedule(dynamic, 1) nowait
+        for (uint32_t y = y0; y < y1; y++) {
+            for (uint32_t x = 0; x < W; x++) {
+                uint32_t pixel_idx = y * W + x;
+                float uvx = (float)x / (float)W, uvy = (float)y / (float)H;
+                float px = uvx - 0.5f, py = (1.0f - uvy) - 0.5f;
+                uint32_t seed = oracle_seed(pixel_idx, ctx->frame);
+                v3 color = V(0.0f, 0.0f, 0.0f);
+                for (uint32_t i = 0; i < ctx->samples; i++) {
+                    uint32_t *fh = (hit_ids && i == 0) ? &hit_ids[2 * (size_t)pixel_idx] : NULL;
+                    color = add(color, sample_path(sc, ctx, &seed, px, py, mode, &cnt, fh));
+                }
+                float ns = (float)ctx->samples;
+                color = V(color.x / ns, color.y / ns, color.z / ns);
+                v3 mapped = tone_map(scale(color, ctx->exposure));
+                float w = 1.0f / (float)(ctx->accumulation_frame + 1u);
+                float *px4 = &accum[4 * (size_t)pixel_idx];
+                v3 old = V(px4[0], px4[1], px4[2]);
+                v3 out = mix3(old, mapped, w);
+                px4[0] = out.x; px4[1] = out.y; px4[2] = out.z;
+                cnt.pixel_frames++;
+            }
+        }
+#pragma omp critical
+        {
+            total.rays += cnt.rays; total.node_visits += cnt.node_visits;
+            total.triangle_tests += cnt.triangle_tests; total.hits += cnt.hits;
+            total.pixel_frames += cnt.pixel_frames;
+        }
+    }
+    if (counters) {
+        counters->rays += total.rays; counters->node_visits += total.node_visits;
+        counters->triangle_tests += total.triangle_tests; counters->hits += total.hits;
+        counters->pixel_frames += total.pixel_frames;
+    }
+}
+
+/* Nearest hit of a single ray, for intersector unit tests.  out = {t,u,v},
+ * ids = {geometry, primitive, front}. Returns 1 on hit. */
+int oracle_trace(const OScene *sc, const float *o, const float *d, int cull, int mode, float *out, uint32_t *ids) {
+    OHit h;
+    OCounters cnt;
+    memset(&cnt, 0, sizeof cnt);
+    v3 oo = V(o[0], o[1], o[2]), dd = V(d[0], d[1], d[2]);
+    if (mode == 0) nearest_brute(sc, oo, dd, 0.001f, 3.40282347e+38f, cull, &h, &cnt);
+    else nearest_bvh(sc, oo, dd, 0.001f, 3.40282347e+38f, cull, &h, &cnt);
+    if (h.id == O_NO_HIT) return 0;
+    out[0] = h.t; out[1] = h.u; out[2] = h.v;
+    if (h.id < sc->n_tris) { ids[0] = sc->tris[h.id].geometry; ids[1] = sc->tris[h.id].primitive; }
+    else { ids[0] = 0x80000000u | (uint32_t)(h.id - sc->n_tris); ids[1] = 0; }
+    ids[2] = (uint32_t)h.front;
+    return 1;
+}
+/* second-nearest distance for the tie policy: smallest t among triangles other
+ * than `skip_id` (global id). Returns INFINITY when none. */
+float oracle_second_nearest(const OScene *sc, const float *o, const float *d, int cull, uint32_t skip_geometry, uint32_t skip_primitive) {
+    v3 oo = V(o[0], o[1], o[2]), dd = V(d[0], d[1], d[2]);
+    float best = INFINITY;
+    for (uint64_t i = 0; i < sc->n_tris; i++) {
+        if (sc->tris[i].geometry == skip_geometry && sc->tris[i].primitive == skip_primitive) continue;
+        float t, u, v, det;
+        if (!tri_test(&sc->tris[i], oo, dd, &t, &u, &v, &det)) continue;
+        int front = sc->front_face_cw ? (det < 0.0f) : (det > 0.0f);
+        if (cull && !front) continue;
+        if (t > 0.001f && t < best) best = t;
+    }
+    return best;
+}
+
+/* Primary ray of sample 0 of pixel (x,y): origin/direction exactly as
+ * sample() generates them (main.wgsl:36-38), for the tie-case classifier. */
+void oracle_primary_ray(const OUniform *ctx, uint32_t x, uint32_t y, float *o, float *d) {
+    uint32_t W = ctx->window[0], H = ctx->window[1];
+    uint32_t pixel_idx = y * W + x;
+    float uvx = (float)x / (float)W, uvy = (float)y / (float)H;
+    float px = uvx - 0.5f, py = (1.0f - uvy) - 0.5f;
+    uint32_t seed = oracle_seed(pixel_idx, ctx->frame);
+    float r0 = oracle_rand(&seed), r1 = oracle_rand(&seed);
+    float offx = (r0 * 2.0f - 1.0f) / (float)W, offy = (r1 * 2.0f - 1.0f) / (float)H;
+    v3 dir = ray_direction(&ctx->camera, px + offx, py + offy);
+    o[0] = ctx->camera.pos[0]; o[1] = ctx->camera.pos[1]; o[2] = ctx->camera.pos[2];
+    d[0] = dir.x; d[1] = dir.y; d[2] = dir.z;
+}
+
+/* ------------------------------------------------- reference SAH BVH2 ----- */
+/* Binned SAH (16 bins), <= 4 triangles per leaf: the "reference SAH BVH2"
+ * SURVEY §8(d) prices algorithmic bytes with. */
+typedef struct { float lo[3], hi[3], c[3]; } OBox;
+
+static void box_grow(float *lo, float *hi, const float *plo, const float *phi) {
+    for (int k = 0; k < 3; k++) { if (plo[k] < lo[k]) lo[k] = plo[k]; if (phi[k] > hi[k]) hi[k] = phi[k]; }
+}
+static float box_area(const float *lo, const float *hi) {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+typedef struct { OScene *sc; const OBox *boxes; uint64_t n_alloc; } OBuild;
+
+static void build_rec(OBuild *b, uint32_t node, uint32_t first, uint32_t count, int depth) {
+    OScene *sc = b->sc;
+    ONode *n = &sc->nodes[node];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = first; i < first + count; i++) {
+        const OBox *bx = &b->boxes[sc->order[i]];
+        box_grow(lo, hi, bx->lo, bx->hi);
+        box_grow(clo, chi, bx->c, bx->c);
+    }
+    memcpy(n->lo, lo, sizeof lo); memcpy(n->hi, hi, sizeof hi);
+    if (count <= 4 || depth >= 100) { n->left = first; n->count = count; return; }
+
+    enum { NB = 16 };
+    int best_axis = -1, best_split = -1;
+    float best_cost = INFINITY;
+    for (int ax = 0; ax < 3; ax++) {
+        float ext = chi[ax] - clo[ax];
+        if (!(ext > 0.0f)) continue;
+        float blo[NB][3], bhi[NB][3]; uint32_t bc[NB];
+        for (int i = 0; i < NB; i++) { bc[i] = 0; for (int k = 0; k < 3; k++) { blo[i][k] = INFINITY; bhi[i][k] = -INFINITY; } }
+        float k1 = (float)NB / ext;
+        for (uint32_t i = first; i < first + count; i++) {
+            const OBox *bx = &b->boxes[sc->order[i]];
+            int bi = (int)((bx->c[ax] - clo[ax]) * k1);
+            if (bi >= NB) bi = NB - 1; if (bi < 0) bi = 0;
+            bc[bi]++; box_grow(blo[bi], bhi[bi], bx->lo, bx->hi);
+        }
+        float rarea[NB]; uint32_t rcount[NB];
+        float rlo[3] = {INFINITY, INFINITY, INFINITY}, rhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t rc = 0;
+        for (int i = NB - 1; i > 0; i--) { box_grow(rlo, rhi, blo[i], bhi[i]); rc += bc[i]; rarea[i] = box_area(rlo, rhi); rcount[i] = rc; }
+        float llo[3] = {INFINITY, INFINITY, INFINITY}, lhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t lc = 0;
+        for (int i = 1; i < NB; i++) {
+            box_grow(llo, lhi, blo[i - 1], bhi[i - 1]); lc += bc[i - 1];
+            if (lc == 0 || rcount[i] == 0) continue;
+            float cost = box_area(llo, lhi) * (float)lc + rarea[i] * (float)rcount[i];
+            if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = i; }
+        }
+    }
+    uint32_t mid;
+    if (best_axis < 0) {
+        mid = first + count / 2; /* all centroids equal: split the list in half */
+    } else {
+        float ext = chi[best_axis] - clo[best_axis];
+        float k1 = (float)NB / ext;
+        uint32_t i = first, j = first + count;
+        while (i < j) {
+            const OBox *bx = &b->boxes[sc->order[i]];
+            int bi = (int)((bx->c[best_axis] - clo[best_axis]) * k1);
+            if (bi >= NB) bi = NB - 1; if (bi < 0) bi = 0;
+            if (bi < best_split) i++;
+            else { j--; uint32_t tmp = sc->order[i]; sc->order[i] = sc->order[j]; sc->order[j] = tmp; }
+        }
+        mid = i;
+        if (mid == first || mid == first + count) mid = first + count / 2;
+    }
+    uint32_t left = (uint32_t)sc->n_nodes;
+    sc->n_nodes += 2;
+    n->left = left; n->count = 0;
+    build_rec(b, left, first, mid - first, depth + 1);
+    build_rec(b, left + 1, mid, first + count - mid, depth + 1);
+}
+
+/* ≙ the BLAS inputs of Scene::finish (src/scene.rs:51-64): triangles are the
+ * index triples of each GeometryPrimitive, positions multiplied by that
+ * geometry's 3x4 transform (row-major; NULL = identity). */
+OScene *oracle_scene_create(const OVertex *vertices, uint64_t n_vertices,
+                            const uint32_t *indices, uint64_t n_indices,
+                            const OPrimitive *prims, uint32_t n_prims, const float *transforms,
+                            const OModel *models, uint32_t n_models,
+                            const OSphere *spheres, uint64_t n_spheres, int build_bvh) {
+    (void)n_vertices; (void)n_indices; (void)n_models;
+    OScene *sc = (OScene *)calloc(1, sizeof *sc);
+    sc->vertices = vertices; sc->indices = indices; sc->models = models;
+    sc->spheres = spheres; sc->n_spheres = n_spheres;
+    uint64_t nt = 0;
+    for (uint32_t g = 0; g < n_prims; g++) nt += prims[g].index_count / 3;
+    sc->n_tris = nt;
+    sc->tris = (OTri *)malloc(sizeof(OTri) * (nt ? nt : 1));
+    uint64_t k = 0;
+    for (uint32_t g = 0; g < n_prims; g++) {
+        const float *m = transforms ? transforms + 12 * prims[g].transformation_offset : NULL;
+        for (uint32_t p = 0; p < prims[g].index_count / 3; p++, k++) {
+            v3 c[3];
+            for (int j = 0; j < 3; j++) {
+                const OVertex *v = &vertices[prims[g].first_vertex + indices[prims[g].first_index + 3 * p + j]];
+                float x = v->position[0], y = v->position[1], z = v->position[2];
+                if (m) c[j] = V(((m[0] * x + m[1] * y) + m[2] * z) + m[3],
+                                ((m[4] * x + m[5] * y) + m[6] * z) + m[7],
+                                ((m[8] * x + m[9] * y) + m[10] * z) + m[11]);
+                else c[j] = V(x, y, z);
+            }
+            sc->tris[k].a = c[0]; sc->tris[k].b = c[1]; sc->tris[k].c = c[2];
+            sc->tris[k].geometry = g; sc->tris[k].primitive = p;
+        }
+    }
+    if (build_bvh && nt > 0) {
+        OBox *boxes = (OBox *)malloc(sizeof(OBox) * nt);
+        sc->order = (uint32_t *)malloc(sizeof(uint32_t) * nt);
+        for (uint64_t i = 0; i < nt; i++) {
+            const OTri *t = &sc->tris[i];
+            const float *pa = &t->a.x, *pb = &t->b.x, *pc = &t->c.x;
+            for (int a = 0; a < 3; a++) {
+                boxes[i].lo[a] = fminf(pa[a], fminf(pb[a], pc[a]));
+                boxes[i].hi[a] = fmaxf(pa[a], fmaxf(pb[a], pc[a]));
+                boxes[i].c[a] = 0.5f * boxes[i].lo[a] + 0.5f * boxes[i].hi[a];
+            }
+            sc->order[i] = (uint32_t)i;
+        }
+        sc->nodes = (ONode *)malloc(sizeof(ONode) * (2 * nt + 1));
+        sc->n_nodes = 1;
+        OBuild b = {sc, boxes, 2 * nt + 1};
+        build_rec(&b, 0, 0, (uint32_t)nt, 0);
+        free(boxes);
+    }
+    return sc;
+}
+void oracle_scene_set_front_face_cw(OScene *sc, int cw) { sc->front_face_cw = cw; }
+uint64_t oracle_scene_triangles(const OScene *sc) { return sc->n_tris; }
+uint64_t oracle_scene_nodes(const OScene *sc) { return sc->n_nodes; }
+void oracle_scene_destroy(OScene *sc) {
+    if (!sc) return;
+    free(sc->tris); free(sc->order); free(sc->nodes); free(sc);
+}
+
+/* Capture ≙ src/ui.rs:86: (x * 255.0) as u8 — Rust float→int `as` truncates
+ * toward zero and saturates; NaN → 0. */
+void oracle_capture_rgb8(const float *accum, uint64_t n_pixels, uint8_t *rgb) {
+    for (uint64_t i = 0; i < n_pixels; i++)
+        for (int k = 0; k < 3; k++) {
+            float v = accum[4 * i + k] * 255.0f;
+            uint8_t b;
+            if (!(v == v)) b = 0; else if (v <= 0.0f) b = 0; else if (v >= 255.0f) b = 255; else b = (uint8_t)v;
+            rgb[3 * i + k] = b;
+        }
+}

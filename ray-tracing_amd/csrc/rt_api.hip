@@ -1,0 +1,585 @@
+// rt_api.hip — implementation of the C ABI in include/rt_abi.h (device half).
+//
+// Owns the device-resident scene (repacked BVH + triangle/shading records +
+// materials), the accumulation buffer and the dispatch of the render kernel.
+// Mirrors the resources the reference binds at /root/reference/src/main.rs:44-54
+// and the per-frame work of App::render, src/app.rs:74-102.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_abi.h"
+#include "../host/rt_host.h"
+#include "rt_device.h"
+#include "rt_math.h"
+
+hipError_t rt_launch_render(const RenderParams &P, bool count, bool aov, hipStream_t stream);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define RT_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+void dev_free(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+}  // namespace
+
+struct rt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // host copy of the scene inputs (models_update rebuilds from them)
+    std::vector<RtVertex> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<RtGeometryPrimitive> primitives;
+    std::vector<float> transforms;   // n_primitives x 12, row-major 3x4
+    std::vector<RtGpuModel> models;
+
+    // device scene
+    DevNode *d_nodes = nullptr;
+    DevTri *d_tris = nullptr;
+    DevShade *d_shade = nullptr;
+    DevMaterial *d_materials = nullptr;
+    uint64_t n_nodes = 0, n_tris = 0;
+    uint32_t stack_entries = 1;
+    bool have_scene = false;
+    double build_seconds = 0.0;
+
+    // accumulation
+    float *d_accum = nullptr;
+    bool accum_owned = false;
+    uint32_t width = 0, height = 0;
+    uint32_t shard_index = 0, shard_count = 1;
+    uint32_t local_bands = 0;
+    bool accum_fresh = false;
+    uint32_t *d_aov = nullptr;
+    uint64_t aov_elems = 0;
+
+    DevCounters *d_counters = nullptr;
+    uint64_t dispatches = 0;
+
+    bool opt_count = false, opt_aov = false, opt_cw = false;
+    int opt_kernel = 0;
+    bool timed = false;
+};
+
+namespace {
+
+uint32_t bands_for(uint32_t h, uint32_t shard_index, uint32_t shard_count) {
+    uint32_t bands = (h + 7u) / 8u;
+    if (bands <= shard_index) return 0;
+    return (bands - shard_index + shard_count - 1u) / shard_count;
+}
+
+// rows the shard actually holds (the last band may be partial)
+uint64_t local_rows_for(uint32_t h, uint32_t shard_index, uint32_t shard_count) {
+    uint32_t lb = bands_for(h, shard_index, shard_count);
+    if (lb == 0) return 0;
+    uint32_t last_band = (lb - 1) * shard_count + shard_index;
+    uint32_t last_rows = h - last_band * 8u;
+    if (last_rows > 8u) last_rows = 8u;
+    return (uint64_t)(lb - 1) * 8u + last_rows;
+}
+
+// Repack the host BVH2 into DevNode/DevTri/DevShade order.  Child boxes are
+// widened by a few ulp so that a hit the triangle test accepts a hair outside
+// its triangle is not culled by the box (tie policy).
+struct Repacked {
+    std::vector<DevNode> nodes;
+    std::vector<DevTri> tris;
+    std::vector<DevShade> shade;
+    uint32_t stack_entries = 1;
+};
+
+inline float pad_lo(float v) { return v - (fabsf(v) * 4.76837158e-7f + 1e-30f); }
+inline float pad_hi(float v) { return v + (fabsf(v) * 4.76837158e-7f + 1e-30f); }
+
+void set_child(DevNode &n, int which, const rt_host::Aabb &box, int32_t ref) {
+    float *lo = which == 0 ? n.lo0 : n.lo1;
+    float *hi = which == 0 ? n.hi0 : n.hi1;
+    for (int k = 0; k < 3; k++) { lo[k] = pad_lo(box.lo[k]); hi[k] = pad_hi(box.hi[k]); }
+    if (which == 0) n.ref0 = ref; else n.ref1 = ref;
+}
+
+void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const std::vector<uint32_t> &ids,
+            const rt_context &ctx, Repacked &out) {
+    const uint64_t n_tris = bvh.order.size();
+    out.tris.resize(n_tris ? n_tris : 1);
+    out.shade.resize(n_tris ? n_tris : 1);
+    memset(out.tris.data(), 0, out.tris.size() * sizeof(DevTri));
+    memset(out.shade.data(), 0, out.shade.size() * sizeof(DevShade));
+    for (uint64_t slot = 0; slot < n_tris; slot++) {
+        const uint32_t gid = bvh.order[slot];
+        const float *c = &corners[9 * (size_t)gid];
+        DevTri &t = out.tris[slot];
+        t.ax = c[0]; t.ay = c[1]; t.az = c[2];
+        t.bx = c[3]; t.by = c[4]; t.bz = c[5];
+        t.cx = c[6]; t.cy = c[7]; t.cz = c[8];
+        t.gid = gid;
+        // shading attributes come from the MODEL's ranges (main.wgsl:86-91),
+        // untransformed (object_to_world is the identity instance transform)
+        const uint32_t g = ids[2 * (size_t)gid], p = ids[2 * (size_t)gid + 1];
+        const RtGpuModel &m = ctx.models[g];
+        const uint32_t is = m.index_start + p * 3u;
+        const RtVertex *v[3];
+        for (int j = 0; j < 3; j++) v[j] = &ctx.vertices[m.vertex_start + ctx.indices[is + j]];
+        DevShade &s = out.shade[slot];
+        memcpy(s.p0, v[0]->position, 12); s.n0x = v[0]->normal[0]; s.n0y = v[0]->normal[1]; s.n0z = v[0]->normal[2]; memcpy(s.uv0, v[0]->uv, 8);
+        memcpy(s.p1, v[1]->position, 12); s.n1x = v[1]->normal[0]; s.n1y = v[1]->normal[1]; s.n1z = v[1]->normal[2]; memcpy(s.uv1, v[1]->uv, 8);
+        memcpy(s.p2, v[2]->position, 12); s.n2x = v[2]->normal[0]; s.n2y = v[2]->normal[1]; s.n2z = v[2]->normal[2]; memcpy(s.uv2, v[2]->uv, 8);
+        s.geometry = g;
+        s.primitive = p;
+    }
+
+    auto leaf_ref = [&](const rt_host::Bvh2Node &n) { return dev_leaf_ref(n.left, n.count); };
+    const rt_host::Bvh2Node &root = bvh.nodes[0];
+    if (root.count > 0 || bvh.nodes.size() == 1) {
+        // the whole scene is one leaf (or empty): a root whose second child is empty
+        out.nodes.resize(1);
+        memset(&out.nodes[0], 0, sizeof(DevNode));
+        rt_host::Aabb box = root.box;
+        if (n_tris == 0) for (int k = 0; k < 3; k++) { box.lo[k] = 0.0f; box.hi[k] = 0.0f; }
+        set_child(out.nodes[0], 0, box, dev_leaf_ref(root.left, n_tris ? root.count : 0));
+        set_child(out.nodes[0], 1, box, dev_leaf_ref(0, 0));
+        out.stack_entries = 2;
+        return;
+    }
+    // depth-first: a node's first child subtree follows it in memory
+    uint64_t n_inner = 0;
+    for (const auto &n : bvh.nodes) if (n.count == 0) n_inner++;
+    out.nodes.resize(n_inner);
+    memset(out.nodes.data(), 0, n_inner * sizeof(DevNode));
+    struct Item { uint32_t src, dst; };
+    std::vector<Item> todo;
+    todo.push_back({0u, 0u});
+    uint32_t next = 1;
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        const rt_host::Bvh2Node &n = bvh.nodes[it.src];
+        DevNode &d = out.nodes[it.dst];
+        const rt_host::Bvh2Node &c0 = bvh.nodes[n.left], &c1 = bvh.nodes[n.left + 1];
+        int32_t r0, r1;
+        uint32_t d0 = 0, d1 = 0;
+        if (c0.count) r0 = leaf_ref(c0); else { d0 = next++; r0 = (int32_t)d0; }
+        if (c1.count) r1 = leaf_ref(c1); else { d1 = next++; r1 = (int32_t)d1; }
+        set_child(d, 0, c0.box, r0);
+        set_child(d, 1, c1.box, r1);
+        if (!c1.count) todo.push_back({n.left + 1, d1});
+        if (!c0.count) todo.push_back({n.left, d0});
+    }
+    out.stack_entries = bvh.max_depth + 2;
+}
+
+int build_and_upload(rt_context *ctx) {
+    std::string err;
+    std::vector<float> corners;
+    std::vector<uint32_t> ids;
+    if (!rt_host::gather_triangles(ctx->vertices.data(), ctx->vertices.size(), ctx->indices.data(), ctx->indices.size(),
+                                   ctx->primitives.data(), (uint32_t)ctx->primitives.size(),
+                                   ctx->transforms.empty() ? nullptr : ctx->transforms.data(), corners, ids, err))
+        return fail(RT_ERR_INVALID_ARGUMENT, "scene: %s", err.c_str());
+    const uint64_t n_tris = ids.size() / 2;
+    // models[] is indexed by geometry_index (main.wgsl:86)
+    if (ctx->models.size() < ctx->primitives.size())
+        return fail(RT_ERR_INVALID_ARGUMENT, "scene: %zu models for %zu geometries", ctx->models.size(), ctx->primitives.size());
+    for (uint64_t t = 0; t < n_tris; t++) {
+        const RtGpuModel &m = ctx->models[ids[2 * t]];
+        uint64_t is = (uint64_t)m.index_start + 3ull * ids[2 * t + 1];
+        if (is + 3 > ctx->indices.size())
+            return fail(RT_ERR_INVALID_ARGUMENT, "scene: model index range exceeds the index buffer");
+        for (int j = 0; j < 3; j++)
+            if ((uint64_t)m.vertex_start + ctx->indices[is + j] >= ctx->vertices.size())
+                return fail(RT_ERR_INVALID_ARGUMENT, "scene: model vertex range exceeds the vertex buffer");
+    }
+    std::vector<rt_host::Aabb> boxes(n_tris);
+    for (uint64_t t = 0; t < n_tris; t++) {
+        const float *c = &corners[9 * t];
+        for (int k = 0; k < 3; k++) {
+            boxes[t].lo[k] = fminf(c[k], fminf(c[3 + k], c[6 + k]));
+            boxes[t].hi[k] = fmaxf(c[k], fmaxf(c[3 + k], c[6 + k]));
+        }
+    }
+    rt_host::Bvh2 bvh;
+    rt_host::BvhBuildOptions opt;
+    rt_host::build_bvh2(boxes.data(), n_tris, opt, bvh);
+    Repacked rp;
+    repack(bvh, corners, ids, *ctx, rp);
+    ctx->build_seconds = bvh.build_seconds;
+
+    std::vector<DevMaterial> mats(ctx->models.size() ? ctx->models.size() : 1);
+    memset(mats.data(), 0, mats.size() * sizeof(DevMaterial));
+    for (size_t i = 0; i < ctx->models.size(); i++) {
+        const RtMaterial &m = ctx->models[i].material;
+        DevMaterial &d = mats[i];
+        memcpy(d.diffuse, m.metal.diffuse_color, 12);
+        memcpy(d.specular, m.metal.specular_color, 12);
+        d.specular_probability = m.metal.specular_probability;
+        d.roughness = m.metal.roughness;
+        for (int k = 0; k < 3; k++) d.emitted[k] = m.metal.emission_color[k] * m.metal.emission_strength;  // main.wgsl:56
+        d.refractive_index = m.refractive_index;
+        d.tag = m.tag;
+    }
+
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
+    RT_HIP(hipMalloc((void **)&ctx->d_nodes, rp.nodes.size() * sizeof(DevNode)));
+    RT_HIP(hipMalloc((void **)&ctx->d_tris, rp.tris.size() * sizeof(DevTri)));
+    RT_HIP(hipMalloc((void **)&ctx->d_shade, rp.shade.size() * sizeof(DevShade)));
+    RT_HIP(hipMalloc((void **)&ctx->d_materials, mats.size() * sizeof(DevMaterial)));
+    RT_HIP(hipMemcpy(ctx->d_nodes, rp.nodes.data(), rp.nodes.size() * sizeof(DevNode), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_tris, rp.tris.data(), rp.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_shade, rp.shade.data(), rp.shade.size() * sizeof(DevShade), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
+    ctx->n_nodes = rp.nodes.size();
+    ctx->n_tris = n_tris;
+    ctx->stack_entries = rp.stack_entries;
+    ctx->have_scene = true;
+    return RT_OK;
+}
+
+int setup_accum(rt_context *ctx, uint32_t w, uint32_t h) {
+    ctx->width = w;
+    ctx->height = h;
+    ctx->local_bands = bands_for(h, ctx->shard_index, ctx->shard_count);
+    ctx->accum_fresh = true;
+    dev_free(ctx->d_aov);
+    ctx->aov_elems = 0;
+    return RT_OK;
+}
+
+int ensure_aov(rt_context *ctx) {
+    uint64_t elems = (uint64_t)ctx->local_bands * 8u * ctx->width;
+    if (ctx->d_aov && ctx->aov_elems == elems) return RT_OK;
+    dev_free(ctx->d_aov);
+    RT_HIP(hipMalloc((void **)&ctx->d_aov, (elems ? elems : 1) * sizeof(RtHitId)));
+    RT_HIP(hipMemsetAsync(ctx->d_aov, 0xFF, (elems ? elems : 1) * sizeof(RtHitId), ctx->stream));
+    ctx->aov_elems = elems;
+    return RT_OK;
+}
+
+int launch(rt_context *ctx, const RtUniform &u) {
+    RenderParams P;
+    memset(&P, 0, sizeof P);
+    P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
+    P.accum = ctx->d_accum;
+    P.aov = ctx->opt_aov ? ctx->d_aov : nullptr;
+    P.counters = ctx->d_counters;
+    P.width = u.window[0]; P.height = u.window[1];
+    P.tiles_x = (P.width + 7u) / 8u;
+    P.local_bands = ctx->local_bands;
+    P.shard_index = ctx->shard_index; P.shard_count = ctx->shard_count;
+    P.frame = u.frame; P.accumulation_frame = u.accumulation_frame; P.flags = u.flags;
+    P.max_bounces = u.max_bounces; P.samples = u.samples;
+    P.stack_entries = ctx->stack_entries;
+    P.front_face_cw = ctx->opt_cw ? 1u : 0u;
+    P.exposure = u.exposure; P.environment = u.environment;
+    memcpy(P.cam_pos, u.camera.position, 12);
+    // camera basis: camera_direction() + ray_direction(), shaders/ray.wgsl:1-10,51-60.
+    // Uniform per dispatch, so evaluated once here with the same RTN-1 arithmetic.
+    float sy, cy, sp, cp;
+    rt_sincos(u.camera.yaw, &sy, &cy);
+    rt_sincos(u.camera.pitch, &sp, &cp);
+    rt_v3 forward = rt_normalize(v3(cy * cp, sp, sy * cp));
+    rt_v3 right = rt_normalize(rt_cross(v3(0.0f, 1.0f, 0.0f), forward));
+    rt_v3 up = rt_normalize(rt_cross(forward, right));
+    float sh, ch;
+    rt_sincos(u.camera.fov * 0.5f, &sh, &ch);
+    P.fov_scale = sh / ch;
+    P.aspect = u.camera.aspect;
+    P.forward[0] = forward.x; P.forward[1] = forward.y; P.forward[2] = forward.z;
+    P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
+    P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
+    RT_HIP(rt_launch_render(P, ctx->opt_count, ctx->opt_aov, ctx->stream));
+    ctx->dispatches++;
+    return RT_OK;
+}
+
+int check_dispatch(rt_context *ctx, const RtUniform *u) {
+    if (!ctx || !u) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "dispatch before rt_scene_upload");
+    if (!ctx->d_accum) return fail(RT_ERR_NO_ACCUM, "dispatch before rt_accum_resize/rt_accum_bind");
+    if (u->window[0] != ctx->width || u->window[1] != ctx->height)
+        return fail(RT_ERR_INVALID_ARGUMENT, "uniform.window %ux%u does not match the accumulation buffer %ux%u",
+                    u->window[0], u->window[1], ctx->width, ctx->height);
+    if ((uint64_t)u->window[0] * u->window[1] > 0xFFFFFFFFull)
+        return fail(RT_ERR_INVALID_ARGUMENT, "window has more than 2^32 pixels");
+    if ((uint64_t)ctx->stack_entries * 256u * 4u > 160u * 1024u)
+        return fail(RT_ERR_INVALID_ARGUMENT, "BVH depth %u needs more LDS than a CU has", ctx->stack_entries);
+    RT_HIP(hipSetDevice(ctx->device));
+    if (ctx->opt_aov) { int r = ensure_aov(ctx); if (r) return r; }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_create(int device_id, rt_context **out) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_id, n - 1);
+    RT_HIP(hipSetDevice(device_id));
+    rt_context *ctx = new rt_context();
+    ctx->device = device_id;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_counters, sizeof(DevCounters)) != hipSuccess ||
+        hipMemset(ctx->d_counters, 0, sizeof(DevCounters)) != hipSuccess) {
+        rt_destroy(ctx);
+        return fail(RT_ERR_HIP, "context set-up failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return RT_OK;
+}
+
+int rt_destroy(rt_context *ctx) {
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
+    if (ctx->accum_owned) dev_free(ctx->d_accum);
+    dev_free(ctx->d_aov); dev_free(ctx->d_counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return RT_OK;
+}
+
+int rt_set_stream(rt_context *ctx, void *hip_stream) {
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RT_OK;
+}
+
+int rt_set_option(rt_context *ctx, int key, int64_t value) {
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    switch (key) {
+        case RT_OPT_COUNT_TRAVERSAL: ctx->opt_count = value != 0; return RT_OK;
+        case RT_OPT_AOV: ctx->opt_aov = value != 0; return RT_OK;
+        case RT_OPT_KERNEL: ctx->opt_kernel = (int)value; return RT_OK;
+        case RT_OPT_FRONT_FACE_CW: ctx->opt_cw = value != 0; return RT_OK;
+        default: return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);
+    }
+}
+
+int rt_scene_upload(rt_context *ctx, const RtVertex *vertices, uint64_t n_vertices, const uint32_t *indices,
+                    uint64_t n_indices, const RtGeometryPrimitive *primitives, uint32_t n_primitives,
+                    const float *transforms, const RtGpuModel *models, uint32_t n_models) {
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if ((n_vertices && !vertices) || (n_indices && !indices) || (n_primitives && !primitives) || (n_models && !models))
+        return fail(RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
+    for (uint32_t g = 0; g < n_primitives; g++)
+        if (transforms && primitives[g].transformation_offset >= n_primitives)
+            return fail(RT_ERR_INVALID_ARGUMENT, "geometry %u: transformation_offset out of range", g);
+    ctx->vertices.assign(vertices, vertices + n_vertices);
+    ctx->indices.assign(indices, indices + n_indices);
+    ctx->primitives.assign(primitives, primitives + n_primitives);
+    ctx->models.assign(models, models + n_models);
+    if (transforms) ctx->transforms.assign(transforms, transforms + 12ull * n_primitives);
+    else ctx->transforms.clear();
+    ctx->have_scene = false;
+    return build_and_upload(ctx);
+}
+
+int rt_spheres_upload(rt_context *ctx, const RtSphere *spheres, uint64_t n_spheres) {
+    (void)spheres;
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (n_spheres == 0) return RT_OK;
+    return fail(RT_ERR_INVALID_ARGUMENT, "sphere primitives are not implemented yet (BASELINE config C4)");
+}
+
+int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models, const float *transforms) {
+    if (!ctx || (n_models && !models)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_models_update before rt_scene_upload");
+    ctx->models.assign(models, models + n_models);
+    if (transforms) ctx->transforms.assign(transforms, transforms + 12ull * ctx->primitives.size());
+    return build_and_upload(ctx);
+}
+
+int rt_set_shard(rt_context *ctx, uint32_t shard_index, uint32_t shard_count) {
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(RT_ERR_INVALID_ARGUMENT, "shard %u of %u", shard_index, shard_count);
+    if (ctx->d_accum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_shard must precede rt_accum_resize/rt_accum_bind");
+    ctx->shard_index = shard_index;
+    ctx->shard_count = shard_count;
+    return RT_OK;
+}
+
+uint64_t rt_accum_local_rows(const rt_context *ctx, uint32_t w, uint32_t h) {
+    (void)w;
+    if (!ctx) return 0;
+    return local_rows_for(h, ctx->shard_index, ctx->shard_count);
+}
+
+int rt_accum_resize(rt_context *ctx, uint32_t w, uint32_t h) {
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->accum_owned) dev_free(ctx->d_accum);
+    ctx->d_accum = nullptr;
+    // whole bands are allocated so a partial last band needs no special case
+    uint64_t bytes = (uint64_t)bands_for(h, ctx->shard_index, ctx->shard_count) * 8u * w * RT_ACCUM_STRIDE_BYTES;
+    RT_HIP(hipMalloc((void **)&ctx->d_accum, bytes ? bytes : 16));
+    RT_HIP(hipMemsetAsync(ctx->d_accum, 0, bytes ? bytes : 16, ctx->stream));   // zeros, src/app.rs:90-92
+    ctx->accum_owned = true;
+    return setup_accum(ctx, w, h);
+}
+
+int rt_accum_bind(rt_context *ctx, void *device_ptr, uint64_t bytes, uint32_t w, uint32_t h) {
+    if (!ctx || !device_ptr) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    uint64_t need = local_rows_for(h, ctx->shard_index, ctx->shard_count) * w * RT_ACCUM_STRIDE_BYTES;
+    if (bytes < need) return fail(RT_ERR_INVALID_ARGUMENT, "accumulation buffer has %llu bytes, needs %llu",
+                                  (unsigned long long)bytes, (unsigned long long)need);
+    if (((uintptr_t)device_ptr & 15u) != 0) return fail(RT_ERR_INVALID_ARGUMENT, "accumulation buffer must be 16-byte aligned");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->accum_owned) dev_free(ctx->d_accum);
+    ctx->d_accum = (float *)device_ptr;
+    ctx->accum_owned = false;
+    return setup_accum(ctx, w, h);
+}
+
+int rt_dispatch(rt_context *ctx, const RtUniform *uniform) {
+    int r = check_dispatch(ctx, uniform);
+    if (r) return r;
+    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    r = launch(ctx, *uniform);
+    if (r) return r;
+    RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    ctx->accum_fresh = false;
+    return RT_OK;
+}
+
+int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames) {
+    int r = check_dispatch(ctx, uniform);
+    if (r) return r;
+    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (uint32_t i = 0; i < n_frames; i++) {
+        uniform->accumulation_frame += 1;                  // src/app.rs:78
+        if (ctx->accum_fresh) {                            // src/app.rs:87-88
+            uniform->accumulation_frame = 0;
+            ctx->accum_fresh = false;
+        }
+        uniform->frame += 1;                               // src/app.rs:96
+        r = launch(ctx, *uniform);
+        if (r) return r;
+    }
+    RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return RT_OK;
+}
+
+int rt_sync(rt_context *ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_accum_download(rt_context *ctx, float *dst) {
+    if (!ctx || !dst) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->d_accum) return fail(RT_ERR_NO_ACCUM, "no accumulation buffer");
+    RT_HIP(hipSetDevice(ctx->device));
+    uint64_t bytes = local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count) * ctx->width * RT_ACCUM_STRIDE_BYTES;
+    RT_HIP(hipMemcpyAsync(dst, ctx->d_accum, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_aov_download(rt_context *ctx, RtHitId *dst) {
+    if (!ctx || !dst) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->d_aov) return fail(RT_ERR_INVALID_ARGUMENT, "no AOV buffer: set RT_OPT_AOV before dispatching");
+    RT_HIP(hipSetDevice(ctx->device));
+    uint64_t bytes = local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count) * ctx->width * sizeof(RtHitId);
+    RT_HIP(hipMemcpyAsync(dst, ctx->d_aov, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_stats(rt_context *ctx, RtStats *out) {
+    if (!ctx || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    DevCounters c;
+    RT_HIP(hipMemcpyAsync(&c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    memset(out, 0, sizeof *out);
+    out->rays = c.rays;
+    out->pixel_frames = c.pixel_frames;
+    out->node_visits = c.node_visits;
+    out->triangle_tests = c.triangle_tests;
+    out->dispatches = ctx->dispatches;
+    out->bvh_nodes = ctx->n_nodes;
+    out->bvh_bytes = ctx->n_nodes * sizeof(DevNode) + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));
+    out->bvh_build_seconds = ctx->build_seconds;
+    return RT_OK;
+}
+
+int rt_stats_reset(rt_context *ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(DevCounters), ctx->stream));
+    ctx->dispatches = 0;
+    return RT_OK;
+}
+
+int rt_last_dispatch_ms(rt_context *ctx, float *ms) {
+    if (!ctx || !ms) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->timed) return fail(RT_ERR_INVALID_ARGUMENT, "no dispatch has been timed yet");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipEventSynchronize(ctx->ev1));
+    RT_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RT_OK;
+}
+
+int rt_host_scene_finish(const rt_host_scene *s, rt_context *ctx) {
+    if (!s || !ctx) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    const rt_host::Scene &sc = s->scene;
+    return rt_scene_upload(ctx, sc.vertices.data(), sc.vertices.size(), sc.indices.data(), sc.indices.size(),
+                           sc.primitives.data(), (uint32_t)sc.primitives.size(), nullptr, sc.models.data(),
+                           (uint32_t)sc.models.size());
+}
+
+}  // extern "C"
+
+// shared with host_api.cpp so host-only entry points report through the same channel
+void rt_set_last_error(const std::string &s) { g_last_error = s; }
