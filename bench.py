@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark: Mrays/s on teapot-circle 3840x2160, 8 bounces
+(BASELINE.json config C3), on N GPUs of one node.
+
+A "step" is one dispatch of the compute pass (one frame of `samples`=16 spp over
+the whole 4K image, src/app.rs:95-101).  With --gpus N the image's 8-row bands
+are dealt round-robin to N ranks (one process per GPU), the scene is replicated,
+and ONE framebuffer gather to rank 0 (RCCL) closes the timed region.  Total work
+is fixed as N grows → "scaling": "strong".
+
+Rays are counted exactly on the device (one count per trace_ray call,
+shaders/main.wgsl:44).  The roofline entry prices the render kernel against HBM
+with SURVEY.md §8(d)'s algorithmic bytes per ray; the cpu_baseline entry times
+the CPU oracle (a port, not lavapipe) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+S_NODE, S_TRI, S_HIT, S_FB = 32, 36, 284, 32   # SURVEY.md §8(d) bytes
+
+
+def cpu_baseline_and_byte_model(cfg, sample_w, sample_h):
+    """Oracle (BVH mode, OpenMP) on a reduced-resolution frame of the same
+    scene/camera/spp: gives the CPU Mrays/s and the per-ray node/triangle means."""
+    from oracle import obj_loader, oracle
+    sc = oracle.OracleScene(obj_loader.load(os.path.join(ROOT, cfg["scene"])))
+    u = oracle.make_uniform(sample_w, sample_h, cfg["position"], cfg["yaw"], cfg["pitch"],
+                            aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]),
+                            max_bounces=cfg["max_bounces"], samples=cfg["samples"])
+    t0 = time.perf_counter()
+    _, _, cnt = sc.render(u, mode=1)
+    dt = time.perf_counter() - t0
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    n_node = cnt.node_visits / cnt.rays
+    n_tri = cnt.triangle_tests / cnt.rays
+    hit = cnt.hits / cnt.rays
+    return {"mrays": cnt.rays / dt / 1e6, "seconds": dt, "rays": cnt.rays, "threads": threads,
+            "n_node": n_node, "n_tri": n_tri, "hit": hit,
+            "bytes_per_ray": n_node * S_NODE + n_tri * S_TRI + hit * S_HIT}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--cpu-sample", default="960x540", help="resolution of the cpu_baseline sample frame")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rt = graft.load_package()
+    sharding = __import__("ray_tracing_amd.sharding", fromlist=["x"])
+    cfg = graft.load_config(args.config)
+    W, H = cfg["width"], cfg["height"]
+
+    hs = rt.HostScene(os.path.join(ROOT, cfg["scene"]))
+    ctx = rt.Context(local_rank)
+    ctx.scene_finish(hs)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    ctx.set_shard(rank, world)
+    local = torch.zeros(sharding.local_buffer_floats(W, H, world), dtype=torch.float32, device=dev)
+
+    def fresh_uniform():
+        u = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], max_bounces=cfg["max_bounces"],
+                            samples=cfg["samples"])
+        u["frame"] = 0                 # cold start, src/main.rs:76-77: first dispatch sees (1, 0)
+        u["accumulation_frame"] = 1
+        return u
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # warm-up: W untimed steps (+ one gather so RCCL's channels exist)
+    ctx.accum_bind(local.data_ptr(), local.numel() * 4, W, H)
+    u = fresh_uniform()
+    if args.warmup > 0:
+        ctx.dispatch_frames(u, args.warmup)
+    img = sharding.gather_framebuffer(local, W, H, rank, world)
+    del img
+    barrier()
+
+    # timed: exactly K steps from a cold accumulation buffer + the final gather
+    local.zero_()
+    ctx.accum_bind(local.data_ptr(), local.numel() * 4, W, H)
+    ctx.stats_reset()
+    u = fresh_uniform()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.dispatch_frames(u, args.steps)
+    img = sharding.gather_framebuffer(local, W, H, rank, world)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    kernel_ms = ctx.last_dispatch_ms() / args.steps        # HIP events on the launch stream, per launch
+    stats = ctx.stats()
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    r = torch.tensor([stats.rays, stats.pixel_frames], dtype=torch.int64, device=dev)
+    k = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    rays, pixel_frames = int(r[0].item()), int(r[1].item())
+    kernel_ms = float(k.item())
+
+    if rank == 0:
+        assert pixel_frames == W * H * args.steps, (pixel_frames, W * H * args.steps)
+        assert img is not None and bool(torch.isfinite(img[..., :3]).all())
+        out = {
+            "metric": "Mrays/s (node) teapot-circle 4K 8-bounce; % of HBM roofline",
+            "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic camera on the reference's scenes/teapot-circle.obj",
+            "config": {"workload": f"{args.config}: {os.path.basename(cfg['scene'])} {W}x{H}, {cfg['samples']} spp/step x {args.steps} steps, "
+                                   f"{cfg['max_bounces']} bounces, 8-row bands round-robin over {world} GPU(s), one framebuffer gather",
+                       "rays": rays, "spp": cfg["samples"] * args.steps,
+                       "spp_per_s": cfg["samples"] * args.steps / dt, "msamples_per_s": W * H * cfg["samples"] * args.steps / dt / 1e6},
+        }
+        cpu = None
+        if not args.no_cpu:
+            sw, sh = (int(x) for x in args.cpu_sample.split("x"))
+            cpu = cpu_baseline_and_byte_model(cfg, sw, sh)
+            out["cpu_baseline"] = {"value": cpu["mrays"], "unit": "Mrays/s", "cores": cpu["threads"], "kind": "port",
+                                   "sample": f"oracle/rt_oracle.c (CPU restatement, not lavapipe), BVH mode, OpenMP; one {sw}x{sh} frame of the "
+                                             f"same scene/camera, {cfg['samples']} spp, {cfg['max_bounces']} bounces: {cpu['rays']} rays in {cpu['seconds']:.2f} s"}
+            rays_per_launch = rays / args.steps / world       # per GPU, per launch
+            algo_bytes = rays_per_launch * cpu["bytes_per_ray"] + (W * H / world) * S_FB
+            achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "rt_render_kernel", "kernel_ms": kernel_ms,
+                               "bytes_per_ray": cpu["bytes_per_ray"], "nodes_per_ray": cpu["n_node"],
+                               "tris_per_ray": cpu["n_tri"], "hit_fraction": cpu["hit"]}
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
