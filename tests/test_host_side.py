@@ -1,0 +1,180 @@
+"""Host half of the library (CPU only): C-ABI exports, scene loader, BVH builder, capture/PNG."""
+import ctypes
+import os
+import re
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+
+def test_library_exports_every_declared_symbol(rt):
+    header = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"rt_context", "rt_host_scene"}
+    assert declared == set(rt.EXPORTS), declared ^ set(rt.EXPORTS)
+    L = ctypes.CDLL(rt.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+
+
+def test_no_gpu_reports_error_not_crash(rt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(rt.RtError) as e:
+        rt.Context(0)
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "teapot", "teapot-circle"])
+def test_cpp_loader_matches_python_restatement(rt, scenes, name):
+    hs = rt.HostScene(scene_path(name))
+    s = scenes(name)
+    for k in ["vertices", "indices", "primitives", "models"]:
+        assert np.array_equal(getattr(hs, k).view(np.uint8), getattr(s, k).view(np.uint8)), k
+    assert hs.names == s.names
+
+
+def _write(tmp_path, obj, mtl="newmtl m\nKd 0.1 0.2 0.3\nKe 3 0 4\nPm 0.25\nPr 0.5\n"):
+    (tmp_path / "s.mtl").write_text(mtl)
+    p = tmp_path / "s.obj"
+    p.write_text("mtllib s.mtl\n" + obj)
+    return str(p)
+
+
+def test_loader_ragged_inputs(rt, obj_loader, tmp_path):
+    # n-gon fan, negative indices, missing vt, shared corners de-duplicated in first-use order, two objects
+    obj = """o A
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0.5 1.5 0
+vn 0 0 1
+usemtl m
+f 1//1 2//1 3//1 4//1 5//1
+o B
+v 0 0 1
+v 1 0 1
+v 0 1 1
+vt 0.25 0.75
+usemtl m
+f -3/1/1 -2/1/1 -1/1/1
+"""
+    path = _write(tmp_path, obj)
+    hs = rt.HostScene(path)
+    s = obj_loader.load(path)
+    for k in ["vertices", "indices", "primitives", "models"]:
+        assert np.array_equal(getattr(hs, k).view(np.uint8), getattr(s, k).view(np.uint8)), k
+    assert list(hs.indices) == [0, 1, 2, 0, 2, 3, 0, 3, 4, 0, 1, 2]
+    assert list(hs.primitives["first_vertex"]) == [0, 5] and list(hs.primitives["index_count"]) == [9, 3]
+    assert (hs.vertices["uv"][:5] == 0).all() and (hs.vertices["uv"][5:] == [0.25, 0.75]).all()
+    m = hs.models[0]
+    assert m["specular_probability"] == np.float32(0.25) and m["roughness"] == np.float32(0.5)
+    assert m["emission_strength"] == np.float32(5.0) and np.allclose(m["emission_color"], [0.6, 0.0, 0.8])
+    assert list(hs.models["vertex_start"]) == [0, 5] and list(hs.models["index_start"]) == [0, 9]
+
+
+def test_loader_errors(rt, tmp_path):
+    with pytest.raises(rt.RtError) as e:
+        rt.HostScene(str(tmp_path / "missing.obj"))
+    assert e.value.code == -7
+    # object without a material: material_id.unwrap() panics in the reference (src/scene.rs:149)
+    p = _write(tmp_path, "o A\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\n")
+    with pytest.raises(rt.RtError) as e:
+        rt.HostScene(p)
+    assert e.value.code == -8 and "material" in str(e.value)
+    p = _write(tmp_path, "o A\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl m\nf 1 2 9\n")
+    with pytest.raises(rt.RtError):
+        rt.HostScene(p)
+
+
+def test_loader_empty_file(rt, tmp_path):
+    p = tmp_path / "e.obj"
+    p.write_text("# nothing\n")
+    hs = rt.HostScene(str(p))
+    assert len(hs.vertices) == 0 and len(hs.indices) == 0 and len(hs.models) == 0
+
+
+@pytest.mark.parametrize("name", ["cornell-box", "teapot", "teapot-circle"])
+def test_bvh_structure_on_scenes(rt, scenes, name):
+    s = scenes(name)
+    info = rt.bvh_info(s.vertices, s.indices, s.primitives)   # self-checks coverage + containment inside
+    assert info.n_triangles == len(s.indices) // 3
+    assert info.max_leaf_size <= 4 and info.max_depth <= 48
+    assert info.n_nodes == 2 * info.n_leaves - 1
+
+
+def _soup(rt, obj_loader, n, rng, degenerate=False):
+    v = np.zeros(3 * n, obj_loader.VERTEX_DTYPE)
+    if degenerate:
+        v["position"] = np.tile(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), (n, 1))
+    else:
+        c = rng.uniform(-10, 10, (n, 1, 3)).astype(np.float32)
+        v["position"] = (c + rng.uniform(-0.3, 0.3, (n, 3, 3)).astype(np.float32)).reshape(-1, 3)
+    v["normal"] = [0, 0, 1]
+    idx = np.arange(3 * n, dtype=np.uint32)
+    pr = np.zeros(1, obj_loader.PRIMITIVE_DTYPE)
+    pr[0] = (0, 3 * n, 0, 3 * n, 0)
+    return v, idx, pr
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 5, 1000, 70000])
+def test_bvh_random_soups(rt, obj_loader, n):
+    v, idx, pr = _soup(rt, obj_loader, n, np.random.default_rng(n))
+    info = rt.bvh_info(v, idx, pr)
+    assert info.n_triangles == n and info.max_leaf_size <= 4
+
+
+def test_bvh_identical_centroids_is_depth_bounded(rt, obj_loader):
+    # 5000 coincident triangles: SAH cannot separate them; the median fallback must bound the depth
+    v, idx, pr = _soup(rt, obj_loader, 5000, None, degenerate=True)
+    info = rt.bvh_info(v, idx, pr)
+    assert info.n_triangles == 5000 and info.max_depth <= 48 and info.max_leaf_size <= 4
+
+
+def test_bvh_rejects_bad_ranges(rt, obj_loader):
+    v, idx, pr = _soup(rt, obj_loader, 4, np.random.default_rng(1))
+    pr["index_count"] = 13
+    with pytest.raises(rt.RtError):
+        rt.bvh_info(v, idx, pr)
+    pr["index_count"] = 12
+    idx[5] = 99
+    with pytest.raises(rt.RtError):
+        rt.bvh_info(v, idx, pr)
+
+
+def test_png_roundtrip(rt, tmp_path):
+    rng = np.random.default_rng(0)
+    w, h = 37, 21
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    path = str(tmp_path / "o.png")
+    rt.write_png(path, rgb, w, h)
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert ihdr == (w, h, 8, 2, 0, 0, 0)
+    raw = zlib.decompress(idat)
+    rows = np.frombuffer(raw, np.uint8).reshape(h, 1 + 3 * w)
+    assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(h, w, 3), rgb)
+
+
+def test_default_uniform(rt):
+    u = rt.default_uniform()   # src/main.rs:73-84, src/camera.rs:112-123
+    assert tuple(u["position"][0]) == (1.0, 1.0, 1.0) and u["fov"][0] == np.float32(np.pi / 2)
+    assert u["frame"][0] == 0 and u["accumulation_frame"][0] == 1 and u["max_bounces"][0] == 10
+    assert u["samples"][0] == 5 and u["exposure"][0] == 1.0 and u["environment"][0] == 1.0 and u["flags"][0] == 0

@@ -1,0 +1,139 @@
+"""What pins the oracle: RNG known answers, layouts, closed-form counts."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_images_identical, config, uniforms_for
+
+
+def test_rng_known_answers(oracle_mod):
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "rng_kat.json")))
+    for case in kat["cases"]:
+        seed, states, floats = oracle_mod.rand_sequence(case["pixel"], case["frame"], 4)
+        assert seed == int(case["seed"], 16)
+        assert states == [int(s, 16) for s in case["states"]]
+        if "float_bits" in case:
+            assert [int(np.float32(f).view(np.uint32)) for f in floats] == [int(b, 16) for b in case["float_bits"]]
+
+
+def test_rng_matches_python_integers(oracle_mod):
+    # independent restatement of shaders/random.wgsl:3-7 + main.wgsl:23 with Python ints
+    for pixel, frame in [(0, 1), (7, 3), (65535, 2), (3840 * 2160 - 1, 16), (2**32 - 1, 2**32 - 1)]:
+        seed = ((pixel * 2479898233) ^ (frame * 98379842)) & 0xFFFFFFFF
+        s0, states, floats = oracle_mod.rand_sequence(pixel, frame, 8)
+        assert s0 == seed
+        for st, f in zip(states, floats):
+            seed = (seed * 747796405 + 2891336453) & 0xFFFFFFFF
+            assert st == seed
+            assert float(f) == (seed >> 9) / float(1 << 23)
+            assert 0.0 <= float(f) < 1.0
+
+
+def test_sincos_contract_accuracy(oracle_mod):
+    # RTN-1 sin/cos against libm in double: far inside Vulkan's 2^-11 absolute allowance
+    xs = np.concatenate([np.linspace(-7, 7, 20001), np.linspace(0, 2 * np.pi, 20001), [0.0, np.pi / 2, np.pi, 1e3]])
+    worst = 0.0
+    for x in xs.astype(np.float32):
+        s, c = oracle_mod.sincos(float(x))
+        worst = max(worst, abs(float(s) - math.sin(float(x))), abs(float(c) - math.cos(float(x))))
+    assert worst < 2.5e-7, worst
+
+
+def test_layouts_match_wgsl(oracle_mod, obj_loader, rt):
+    # SURVEY.md §8b offsets; the oracle's dtypes were written from types.wgsl, the binding's from rt_abi.h
+    assert oracle_mod.UNIFORM_DTYPE.itemsize == rt.UNIFORM_DTYPE.itemsize == 80
+    o = {n: oracle_mod.UNIFORM_DTYPE.fields[n][1] for n in oracle_mod.UNIFORM_DTYPE.names}
+    assert o == {"window": 0, "position": 16, "pitch": 28, "yaw": 32, "fov": 36, "aspect": 40, "frame": 48,
+                 "accumulation_frame": 52, "flags": 56, "exposure": 60, "enviroment": 64, "max_bounces": 68, "samples": 72}
+    r = {n: rt.UNIFORM_DTYPE.fields[n][1] for n in rt.UNIFORM_DTYPE.names}
+    assert sorted(r.values()) == sorted(o.values())
+    for a, b in [(obj_loader.VERTEX_DTYPE, rt.VERTEX_DTYPE), (obj_loader.MODEL_DTYPE, rt.MODEL_DTYPE),
+                 (obj_loader.PRIMITIVE_DTYPE, rt.PRIMITIVE_DTYPE)]:
+        assert a.itemsize == b.itemsize
+        assert {n: a.fields[n][1] for n in a.names} == {n: b.fields[n][1] for n in b.names}
+    assert obj_loader.VERTEX_DTYPE.itemsize == 48 and obj_loader.MODEL_DTYPE.itemsize == 128
+    m = {n: obj_loader.MODEL_DTYPE.fields[n][1] for n in obj_loader.MODEL_DTYPE.names}
+    assert m["diffuse_color"] == 16 and m["specular_color"] == 32 and m["specular_probability"] == 44
+    assert m["roughness"] == 48 and m["emission_color"] == 64 and m["emission_strength"] == 76
+    assert m["diffuse_texture"] == 80 and m["normal_texture"] == 84 and m["refractive_index"] == 96
+    assert m["vertex_start"] == 112 and m["index_start"] == 116
+
+
+def test_abi_header_compiles_with_static_asserts():
+    import subprocess
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", os.path.join(ROOT, "include", "rt_abi.h")])
+    subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "rt_abi.h")])
+
+
+def test_scene_counts(scenes):
+    # triangles / vertices / models per scene
+    expect = {"cornell-box": (9452, 4747, 8), "teapot": (9954, 5016, 4), "teapot-circle": (10926, 5634, 5)}
+    for name, (tris, verts, models) in expect.items():
+        s = scenes(name)
+        assert (len(s.indices) // 3, len(s.vertices), len(s.models)) == (tris, verts, models)
+    cb = scenes("cornell-box")
+    # cornell light: Ke 10 10 10 → strength sqrt(300), colour 1/sqrt(3) (src/scene.rs:191-192)
+    assert cb.models["emission_strength"][7] == np.float32(np.sqrt(np.float32(300.0)))
+    assert np.allclose(cb.models["emission_color"][7], 0.57735026)
+    assert (cb.models["specular_probability"] == 0).all() and (cb.models["roughness"] == 0).all()
+
+
+def test_closed_box_ray_count_and_brute_vs_bvh(oracle_mod, oracle_scenes):
+    # cornell box is closed and nothing absorbs: every path runs max_bounces+1 segments
+    cfg = config("C1")
+    sc = oracle_scenes("cornell-box")
+    u = uniforms_for(oracle_mod, cfg, 48, 40, samples=3)
+    a_bvh, h_bvh, c_bvh = sc.render(u, mode=1, want_hits=True)
+    a_bf, h_bf, c_bf = sc.render(u, mode=0, want_hits=True)
+    assert c_bvh.rays == c_bf.rays == 48 * 40 * 3 * (cfg["max_bounces"] + 1)
+    assert c_bvh.hits == c_bvh.rays
+    assert np.array_equal(h_bvh, h_bf)
+    assert_images_identical(a_bvh, a_bf, "oracle BVH vs brute force")
+    assert (h_bf[..., 0] < 8).all()
+
+
+@pytest.mark.parametrize("name", ["c1_64", "c2_96x54", "c3_96x54"])
+def test_oracle_bvh_mode_reproduces_golden(oracle_mod, oracle_scenes, name):
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    w, h, spp, frames = (int(x) for x in g["meta"])
+    cname = {"c1": "C1", "c2": "C2", "c3": "C3"}[name[:2]]
+    cfg = config(cname)
+    sc = oracle_scenes(os.path.basename(cfg["scene"])[:-4])
+    u = uniforms_for(oracle_mod, cfg, w, h, samples=spp)
+    accum, cnt = sc.render_frames(u, frames, mode=1)
+    assert cnt.rays == int(g["rays"])
+    assert_images_identical(accum, g["accum"], name)
+    u["frame"] = 1
+    u["accumulation_frame"] = 0
+    _, hits, _ = sc.render(u, mode=1, want_hits=True)
+    assert np.array_equal(hits, g["hits"])
+
+
+def test_tone_map_and_accumulate(oracle_mod, oracle_scenes):
+    # frame 2 blends with weight 1/2 AFTER tone mapping (shaders/main.wgsl:29-31)
+    cfg = config("C1")
+    sc = oracle_scenes("cornell-box")
+    u = uniforms_for(oracle_mod, cfg, 16, 16, samples=2)
+    f1, _, _ = sc.render(u)
+    u2 = u.copy()
+    u2["frame"] = 2
+    f2_alone, _, _ = sc.render(u2)
+    u2["accumulation_frame"] = 1
+    both = f1.copy()
+    sc.render(u2, both)
+    want = f1 * np.float32(0.5) + f2_alone * np.float32(0.5)
+    assert_images_identical(both[..., :3], want[..., :3], "running mean")
+    assert (f1[..., :3] >= 0).all() and (f1[..., :3] <= 1).all()
+
+
+def test_capture_conversion(oracle_mod, rt):
+    # (x * 255.0) as u8: truncate, saturate, NaN -> 0 (src/ui.rs:86)
+    vals = np.array([0.0, 0.5, 1.0, 0.999, 1.5, -0.2, np.nan, 1 / 255, 254.9999 / 255], np.float32)
+    acc = np.zeros((len(vals), 4), np.float32)
+    acc[:, 0] = vals
+    want = [0, 127, 255, 254, 255, 0, 0, 1, 254]
+    assert list(oracle_mod.capture_rgb8(acc)[:, 0]) == want
+    assert list(rt.capture_rgb8(acc)[:, 0]) == want
