@@ -149,6 +149,9 @@ typedef struct RtStats {
     uint64_t pixel_frames;    /* invocations of `main` that passed the bounds check */
     uint64_t node_visits;     /* only counted when RT_OPT_COUNT_TRAVERSAL is set */
     uint64_t triangle_tests;  /* idem */
+    uint64_t wave_node_iters; /* idem: node-loop iterations summed over wavefronts (x64 = lane slots) */
+    uint64_t wave_leaf_iters; /* idem: triangle-loop iterations summed over wavefronts */
+    uint64_t wave_steps;      /* idem: (trace, shade) steps summed over wavefronts */
     uint64_t dispatches;
     uint64_t bvh_nodes;       /* static: nodes in the device BVH */
     uint64_t bvh_bytes;       /* static: bytes of nodes + triangle records on device */

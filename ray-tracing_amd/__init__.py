@@ -62,7 +62,8 @@ EXPORTS = [
 
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("pixel_frames", C.c_uint64), ("node_visits", C.c_uint64),
-                ("triangle_tests", C.c_uint64), ("dispatches", C.c_uint64), ("bvh_nodes", C.c_uint64),
+                ("triangle_tests", C.c_uint64), ("wave_node_iters", C.c_uint64), ("wave_leaf_iters", C.c_uint64),
+                ("wave_steps", C.c_uint64), ("dispatches", C.c_uint64), ("bvh_nodes", C.c_uint64),
                 ("bvh_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double)]
 
 

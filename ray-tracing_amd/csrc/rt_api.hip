@@ -20,7 +20,8 @@
 #include "rt_device.h"
 #include "rt_math.h"
 
-hipError_t rt_launch_render(const RenderParams &P, bool count, bool aov, hipStream_t stream);
+hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, int persistent_blocks, hipStream_t stream);
+int rt_persistent_blocks(int device, uint32_t stack_entries);
 
 namespace {
 
@@ -84,10 +85,13 @@ struct rt_context {
     uint64_t aov_elems = 0;
 
     DevCounters *d_counters = nullptr;
+    DevQueue *d_queue = nullptr;
+    int persistent_blocks = 0;
     uint64_t dispatches = 0;
 
     bool opt_count = false, opt_aov = false, opt_cw = false;
-    int opt_kernel = 0;
+    int opt_kernel = 2;
+    int32_t tune[8] = {4, 4, 2, 8, 0, 0, 0, 0};
     bool timed = false;
 };
 
@@ -123,10 +127,15 @@ inline float pad_lo(float v) { return v - (fabsf(v) * 4.76837158e-7f + 1e-30f); 
 inline float pad_hi(float v) { return v + (fabsf(v) * 4.76837158e-7f + 1e-30f); }
 
 void set_child(DevNode &n, int which, const rt_host::Aabb &box, int32_t ref) {
-    float *lo = which == 0 ? n.lo0 : n.lo1;
-    float *hi = which == 0 ? n.hi0 : n.hi1;
+    float lo[3], hi[3];
     for (int k = 0; k < 3; k++) { lo[k] = pad_lo(box.lo[k]); hi[k] = pad_hi(box.hi[k]); }
-    if (which == 0) n.ref0 = ref; else n.ref1 = ref;
+    if (which == 0) {
+        n.lo0x = lo[0]; n.lo0y = lo[1]; n.lo0z = lo[2]; n.hi0x = hi[0]; n.hi0y = hi[1]; n.hi0z = hi[2];
+        n.ref0 = ref;
+    } else {
+        n.lo1x = lo[0]; n.lo1y = lo[1]; n.lo1z = lo[2]; n.hi1x = hi[0]; n.hi1y = hi[1]; n.hi1z = hi[2];
+        n.ref1 = ref;
+    }
 }
 
 void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const std::vector<uint32_t> &ids,
@@ -141,8 +150,8 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         const float *c = &corners[9 * (size_t)gid];
         DevTri &t = out.tris[slot];
         t.ax = c[0]; t.ay = c[1]; t.az = c[2];
-        t.bx = c[3]; t.by = c[4]; t.bz = c[5];
-        t.cx = c[6]; t.cy = c[7]; t.cz = c[8];
+        t.e1x = c[3] - c[0]; t.e1y = c[4] - c[1]; t.e1z = c[5] - c[2];   // e1 = b - a
+        t.e2x = c[6] - c[0]; t.e2y = c[7] - c[1]; t.e2z = c[8] - c[2];   // e2 = c - a
         t.gid = gid;
         // shading attributes come from the MODEL's ranges (main.wgsl:86-91),
         // untransformed (object_to_world is the identity instance transform)
@@ -263,6 +272,7 @@ int build_and_upload(rt_context *ctx) {
     ctx->n_nodes = rp.nodes.size();
     ctx->n_tris = n_tris;
     ctx->stack_entries = rp.stack_entries;
+    ctx->persistent_blocks = 0;
     ctx->have_scene = true;
     return RT_OK;
 }
@@ -319,7 +329,13 @@ int launch(rt_context *ctx, const RtUniform &u) {
     P.forward[0] = forward.x; P.forward[1] = forward.y; P.forward[2] = forward.z;
     P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
     P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
-    RT_HIP(rt_launch_render(P, ctx->opt_count, ctx->opt_aov, ctx->stream));
+    P.queue = ctx->d_queue;
+    memcpy(P.tune, ctx->tune, sizeof P.tune);
+    if (ctx->opt_kernel != 1) {
+        RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
+        if (ctx->persistent_blocks == 0) ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries);
+    }
+    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, ctx->persistent_blocks, ctx->stream));
     ctx->dispatches++;
     return RT_OK;
 }
@@ -359,6 +375,7 @@ int rt_create(int device_id, rt_context **out) {
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc((void **)&ctx->d_counters, sizeof(DevCounters)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_queue, sizeof(DevQueue)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, sizeof(DevCounters)) != hipSuccess) {
         rt_destroy(ctx);
         return fail(RT_ERR_HIP, "context set-up failed: %s", hipGetErrorString(hipGetLastError()));
@@ -374,7 +391,7 @@ int rt_destroy(rt_context *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
     if (ctx->accum_owned) dev_free(ctx->d_accum);
-    dev_free(ctx->d_aov); dev_free(ctx->d_counters);
+    dev_free(ctx->d_aov); dev_free(ctx->d_counters); dev_free(ctx->d_queue);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -397,7 +414,9 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
         case RT_OPT_AOV: ctx->opt_aov = value != 0; return RT_OK;
         case RT_OPT_KERNEL: ctx->opt_kernel = (int)value; return RT_OK;
         case RT_OPT_FRONT_FACE_CW: ctx->opt_cw = value != 0; return RT_OK;
-        default: return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);
+        default:
+            if (key >= 100 && key < 108) { ctx->tune[key - 100] = (int32_t)value; return RT_OK; }
+            return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);
     }
 }
 
@@ -547,6 +566,9 @@ int rt_stats(rt_context *ctx, RtStats *out) {
     out->pixel_frames = c.pixel_frames;
     out->node_visits = c.node_visits;
     out->triangle_tests = c.triangle_tests;
+    out->wave_node_iters = c.wave_node_iters;
+    out->wave_leaf_iters = c.wave_leaf_iters;
+    out->wave_steps = c.wave_steps;
     out->dispatches = ctx->dispatches;
     out->bvh_nodes = ctx->n_nodes;
     out->bvh_bytes = ctx->n_nodes * sizeof(DevNode) + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));

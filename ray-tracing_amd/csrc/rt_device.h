@@ -8,7 +8,7 @@
 //   DevNode   64 B  one BVH2 inner node holding BOTH children's boxes and
 //                   references, so one visit = one 64-B fetch (half a 128-B
 //                   L2 line) and decides both children;
-//   DevTri    48 B  the three corner positions in leaf order + global id;
+//   DevTri    48 B  corner + two edge vectors in leaf order + global id;
 //   DevShade 128 B  everything trace_ray's attribute part needs
 //                   (shaders/main.wgsl:86-101) for one triangle, one L2 line,
 //                   instead of the reference's 12 B + 3x48 B + 128 B gathers;
@@ -16,11 +16,14 @@
 #pragma once
 #include <stdint.h>
 
+// Field order pairs the planes so that the slab test is six packed FMAs
+// (v_pk_fma_f32) against the constant pairs (ix,iy), (iz,ix), (iy,iz).
 struct alignas(16) DevNode {
-    float lo0[3]; int32_t ref0;   // child 0: box min, reference
-    float hi0[3]; int32_t ref1;   // child 0: box max; child 1 reference
-    float lo1[3]; uint32_t pad0;  // child 1: box min
-    float hi1[3]; uint32_t pad1;  // child 1: box max
+    float lo0x, lo0y, lo0z, hi0x;   // child 0 box
+    float hi0y, hi0z, lo1x, lo1y;   // child 0 box / child 1 box
+    float lo1z, hi1x, hi1y, hi1z;   // child 1 box
+    int32_t ref0, ref1;             // child references
+    uint32_t pad0, pad1;
 };
 static_assert(sizeof(DevNode) == 64, "DevNode");
 
@@ -30,10 +33,12 @@ static inline int32_t dev_leaf_ref(uint32_t first_slot, uint32_t count) {
     return (int32_t)~((first_slot << 3) | count);
 }
 
+// corner a and the two edges e1 = b - a, e2 = c - a (the f32 differences the
+// contract's triangle test starts with, taken once at upload)
 struct alignas(16) DevTri {
-    float ax, ay, az, bx;
-    float by, bz, cx, cy;
-    float cz; uint32_t gid; uint32_t pad0, pad1;   // gid = triangle's place in index-buffer order (tie-break key)
+    float ax, ay, az, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z; uint32_t gid; uint32_t pad0, pad1;   // gid = triangle's place in index-buffer order (tie-break key)
 };
 static_assert(sizeof(DevTri) == 48, "DevTri");
 
@@ -56,6 +61,14 @@ static_assert(sizeof(DevMaterial) == 64, "DevMaterial");
 
 struct DevCounters {
     unsigned long long rays, pixel_frames, node_visits, triangle_tests;
+    unsigned long long wave_node_iters, wave_leaf_iters, wave_steps;
+    unsigned long long pad;
+};
+
+// persistent-kernel work queue head: next unclaimed pixel slot of the launch
+struct DevQueue {
+    unsigned int head;
+    unsigned int pad[3];
 };
 
 struct RenderParams {
@@ -66,6 +79,7 @@ struct RenderParams {
     float *accum;            // local rows x W x 4 f32
     uint32_t *aov;           // local rows x W x 2 u32, or null
     DevCounters *counters;
+    DevQueue *queue;         // persistent variant only; zeroed before each launch
 
     uint32_t width, height;      // uniform.window
     uint32_t tiles_x;            // ceil(W / 8)
@@ -79,4 +93,5 @@ struct RenderParams {
     float cam_pos[3];
     float forward[3], right[3], up[3];   // ray_direction's basis (shaders/ray.wgsl:2-4), hoisted to the host
     float aspect, fov_scale;             // ctx.camera.aspect, tan(fov/2) (shaders/ray.wgsl:6-7)
+    int32_t tune[8];                     // scheduler tunables (experiments)
 };

@@ -1,4 +1,4 @@
-// rt_kernels.hip — the compute pass of the reference, as a gfx950 kernel.
+// rt_kernels.hip — the compute pass of the reference, as gfx950 kernels.
 //
 // Replaces the WGSL entry point `main` and everything it calls
 // (/root/reference/shaders/main.wgsl:14-118, ray.wgsl, random.wgsl, misc.wgsl)
@@ -6,16 +6,24 @@
 // CDNA4 has no hardware: traversal is a software while-while loop over the
 // host-built BVH2 with a per-lane stack in LDS.
 //
-// Work mapping: one wavefront (64 lanes) = one 8x8 pixel tile — the reference's
-// workgroup shape (main.wgsl:15) — one lane per pixel-frame.  RNG state chains
-// across the samples of a pixel (main.wgsl:23-26), so a lane owns its pixel for
-// the whole dispatch; inside the lane the sample and bounce loops are flattened
-// into one loop of (trace, shade) steps so that a lane whose path ended starts
-// its next sample at once instead of idling until the wave's longest path ends.
+// Unit of work = one pixel-frame (one invocation of `main`): the RNG state
+// chains across the samples of a pixel (main.wgsl:23-26), so samples of one
+// pixel cannot be split over lanes.  Inside a lane the sample and bounce loops
+// are flattened into one loop of (trace, shade) steps, so a lane whose path
+// ended starts its next sample at once.
+//
+// Variant 0 (default) — persistent wavefronts with a work queue: the grid is
+//   sized to fill the chip once; each wave claims chunks of 256 pixel slots
+//   from a global head with one atomic, and hands slots to its lanes as they
+//   finish (ballot of idle lanes → prefix rank), so a lane that drew sky
+//   pixels keeps pulling work while its neighbours grind through 9-bounce paths.
+// Variant 1 — one wave per 8x8 tile, one lane per pixel, the reference's own
+//   mapping (main.wgsl:15); kept for A/B measurements.
 //
 // Arithmetic follows the RTN-1 contract (rt_math.h): results are bit-identical
 // to oracle/rt_oracle.c.  Only the ray/box test is free to differ (it must be
-// conservative, nothing more), so it uses v_rcp_f32 and a widened far bound.
+// conservative, nothing more), so it uses v_rcp_f32, packed FMAs and a widened
+// far bound.
 #include <hip/hip_runtime.h>
 
 #include "rt_device.h"
@@ -23,10 +31,13 @@
 
 namespace {
 
-constexpr int kBlock = 256;   // 4 waves = 4 tiles per workgroup
+constexpr int kBlock = 256;                  // 4 waves per workgroup
+constexpr uint32_t kChunk = 256;             // pixel slots a wave claims per atomic (4 tiles)
 constexpr float kTMin = 0.001f;              // main.wgsl:77
 constexpr float kTMax = 3.40282347e+38f;     // main.wgsl:77
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct Hit {
     float t, u, v;
@@ -35,92 +46,125 @@ struct Hit {
     bool front;
 };
 
-__device__ __forceinline__ float4 ld4(const void *p) { return *reinterpret_cast<const float4 *>(p); }
+struct Tally {      // per-lane counters; the wave-level ones only in counting builds
+    unsigned rays = 0, pixel_frames = 0, nodes = 0, tris = 0, w_nodes = 0, w_leaf = 0, w_steps = 0;
+};
 
-// ray/triangle test of the contract (Moller-Trumbore, explicit fmaf); mirrors
-// tri_test()/consider_tri() of the oracle decision for decision.
+__device__ __forceinline__ float4 ld4(const void *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ bool first_active_lane() {
+    unsigned long long m = __ballot(1);
+    return (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)m) - 1);
+}
+
+// ray/triangle test of the contract (Moller-Trumbore, explicit fmaf); same
+// decisions as tri_test()/consider_tri() of the oracle, evaluated branch-free.
+__device__ __forceinline__ void intersect_tri(const DevTri *__restrict__ tris, uint32_t slot, rt_v3 o, rt_v3 d, bool cull,
+                                              bool cw, Hit &best) {
+    const DevTri *tp = tris + slot;
+    float4 q0 = ld4(&tp->ax), q1 = ld4(&tp->e1y), q2 = ld4(&tp->e2z);
+    rt_v3 a = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
+    uint32_t gid = __float_as_uint(q2.y);
+    rt_v3 p = rt_cross_fma(d, e2);
+    float det = rt_dot_fma(e1, p);
+    float inv = 1.0f / det;
+    rt_v3 tv = o - a;
+    float u = rt_dot_fma(tv, p) * inv;
+    rt_v3 q = rt_cross_fma(tv, e1);
+    float v = rt_dot_fma(d, q) * inv;
+    float t = rt_dot_fma(e2, q) * inv;
+    bool front = cw ? (det < 0.0f) : (det > 0.0f);
+    bool ok = (det > 0.0f || det < 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > kTMin) &
+              (!cull | front) & ((t < best.t) | ((t == best.t) & (gid < best.gid)));
+    if (ok) {
+        best.t = t; best.u = u; best.v = v; best.slot = slot; best.gid = gid; best.front = front;
+    }
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void intersect_leaf(const DevTri *__restrict__ tris, uint32_t first, uint32_t count,
-                                               rt_v3 o, rt_v3 d, bool cull, bool cw, Hit &best,
-                                               unsigned &n_tri) {
+                                               rt_v3 o, rt_v3 d, bool cull, bool cw, Hit &best, Tally &tl) {
     for (uint32_t i = 0; i < count; i++) {
-        const DevTri *tp = tris + first + i;
-        float4 q0 = ld4(&tp->ax), q1 = ld4(&tp->by), q2 = ld4(&tp->cz);
-        if (COUNT) n_tri++;
-        rt_v3 a = v3(q0.x, q0.y, q0.z), b = v3(q0.w, q1.x, q1.y), c = v3(q1.z, q1.w, q2.x);
-        uint32_t gid = __float_as_uint(q2.y);
-        rt_v3 e1 = b - a, e2 = c - a;
-        rt_v3 p = rt_cross_fma(d, e2);
-        float det = rt_dot_fma(e1, p);
-        if (!(det > 0.0f || det < 0.0f)) continue;
-        bool front = cw ? (det < 0.0f) : (det > 0.0f);
-        if (cull && !front) continue;
-        float inv = 1.0f / det;
-        rt_v3 tv = o - a;
-        float u = rt_dot_fma(tv, p) * inv;
-        if (!(u >= 0.0f && u <= 1.0f)) continue;
-        rt_v3 q = rt_cross_fma(tv, e1);
-        float v = rt_dot_fma(d, q) * inv;
-        if (!(v >= 0.0f && u + v <= 1.0f)) continue;
-        float t = rt_dot_fma(e2, q) * inv;
-        if (!(t > kTMin)) continue;
-        if (t < best.t || (t == best.t && gid < best.gid)) {
-            best.t = t; best.u = u; best.v = v; best.slot = first + i; best.gid = gid; best.front = front;
-        }
+        if (COUNT) { tl.tris++; if (first_active_lane()) tl.w_leaf++; }
+        intersect_tri(tris, first + i, o, d, cull, cw, best);
     }
+}
+
+// Slab-test constants of one ray (outside the arithmetic contract; conservative):
+//   t = plane * inv - o * inv as one FMA.  inv comes from v_rcp_f32 (1 ulp); a zero
+//   direction component is nudged to 1e-30 so no inf/NaN appears.  The error of t is
+//   <= 2^-24 |o*inv| + 2^-22 |t|, covered by eps (absolute) and the 1.000001 factor.
+struct Slab {
+    f2 ixy, izx, iyz, oxy, ozx, oyz;
+    float eps;
+};
+__device__ __forceinline__ Slab make_slab(rt_v3 o, rt_v3 d) {
+    auto nz = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x; };
+    const float ix = __builtin_amdgcn_rcpf(nz(d.x)), iy = __builtin_amdgcn_rcpf(nz(d.y)), iz = __builtin_amdgcn_rcpf(nz(d.z));
+    const float ox = -(o.x * ix), oy = -(o.y * iy), oz = -(o.z * iz);
+    Slab s;
+    s.eps = 4.76837158e-7f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+    s.ixy = mk2(ix, iy); s.izx = mk2(iz, ix); s.iyz = mk2(iy, iz);
+    s.oxy = mk2(ox, oy); s.ozx = mk2(oz, ox); s.oyz = mk2(oy, oz);
+    return s;
+}
+// both children of one node: entry distances n0/n1 and hit flags
+__device__ __forceinline__ void test_node(const DevNode *n, const Slab &sl, float tbest, bool &h0, bool &h1, float &n0,
+                                          float &n1, int2 &refs) {
+    float4 a = ld4(&n->lo0x), b = ld4(&n->hi0y), c = ld4(&n->lo1z);
+    refs = *reinterpret_cast<const int2 *>(&n->ref0);
+    f2 t0 = __builtin_elementwise_fma(mk2(a.x, a.y), sl.ixy, sl.oxy);   // child 0: lo.x lo.y
+    f2 t1 = __builtin_elementwise_fma(mk2(a.z, a.w), sl.izx, sl.ozx);   //          lo.z hi.x
+    f2 t2 = __builtin_elementwise_fma(mk2(b.x, b.y), sl.iyz, sl.oyz);   //          hi.y hi.z
+    f2 s0 = __builtin_elementwise_fma(mk2(b.z, b.w), sl.ixy, sl.oxy);   // child 1: lo.x lo.y
+    f2 s1 = __builtin_elementwise_fma(mk2(c.x, c.y), sl.izx, sl.ozx);   //          lo.z hi.x
+    f2 s2 = __builtin_elementwise_fma(mk2(c.z, c.w), sl.iyz, sl.oyz);   //          hi.y hi.z
+    n0 = fmaxf(fmaxf(fminf(t0.x, t1.y), fminf(t0.y, t2.x)), fmaxf(fminf(t1.x, t2.y), kTMin));
+    float f0 = fminf(fminf(fmaxf(t0.x, t1.y), fmaxf(t0.y, t2.x)), fminf(fmaxf(t1.x, t2.y), tbest));
+    n1 = fmaxf(fmaxf(fminf(s0.x, s1.y), fminf(s0.y, s2.x)), fmaxf(fminf(s1.x, s2.y), kTMin));
+    float f1 = fminf(fminf(fmaxf(s0.x, s1.y), fmaxf(s0.y, s2.x)), fminf(fmaxf(s1.x, s2.y), tbest));
+    h0 = n0 <= fmaf(f0, 1.000001f, sl.eps);
+    h1 = n1 <= fmaf(f1, 1.000001f, sl.eps);
 }
 
 // nearest committed hit in (kTMin, kTMax): the ray query of main.wgsl:79-83
 template <bool COUNT>
-__device__ __forceinline__ Hit trace(const RenderParams &P, uint32_t *__restrict__ stack, rt_v3 o, rt_v3 d,
-                                     unsigned &n_node, unsigned &n_tri) {
+__device__ __forceinline__ Hit trace(const RenderParams &P, uint32_t *__restrict__ stack, rt_v3 o, rt_v3 d, Tally &tl) {
     Hit best;
     best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
     const bool cull = (P.flags & 1u) != 0;   // flags = 0x10 * (ctx.flags & 1), main.wgsl:76
     const bool cw = P.front_face_cw != 0;
-    // box test only: approximate reciprocal is fine, the far bound is widened
-    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+
+    const Slab sl = make_slab(o, d);
     const DevNode *__restrict__ nodes = P.nodes;
 
     int sp = 0;
     int32_t cur = 0;   // root is always an inner node
     for (;;) {
         while (cur >= 0) {
-            const DevNode *n = nodes + cur;
-            float4 a = ld4(&n->lo0[0]), b = ld4(&n->hi0[0]), c = ld4(&n->lo1[0]), e = ld4(&n->hi1[0]);
-            if (COUNT) n_node++;
-            float t0x = (a.x - o.x) * ix, t1x = (b.x - o.x) * ix;
-            float t0y = (a.y - o.y) * iy, t1y = (b.y - o.y) * iy;
-            float t0z = (a.z - o.z) * iz, t1z = (b.z - o.z) * iz;
-            float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
-            float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
-            float s0x = (c.x - o.x) * ix, s1x = (e.x - o.x) * ix;
-            float s0y = (c.y - o.y) * iy, s1y = (e.y - o.y) * iy;
-            float s0z = (c.z - o.z) * iz, s1z = (e.z - o.z) * iz;
-            float n1 = fmaxf(fmaxf(fminf(s0x, s1x), fminf(s0y, s1y)), fmaxf(fminf(s0z, s1z), kTMin));
-            float f1 = fminf(fminf(fmaxf(s0x, s1x), fmaxf(s0y, s1y)), fminf(fmaxf(s0z, s1z), best.t));
-            bool h0 = n0 <= f0 * 1.000002f;
-            bool h1 = n1 <= f1 * 1.000002f;
-            int32_t r0 = __float_as_int(a.w), r1 = __float_as_int(b.w);
+            if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
+            bool h0, h1;
+            float n0, n1;
+            int2 refs;
+            test_node(nodes + cur, sl, best.t, h0, h1, n0, n1, refs);
             if (h0 && h1) {
                 bool swap = n1 < n0;
-                int32_t nearc = swap ? r1 : r0, farc = swap ? r0 : r1;
+                int32_t nearc = swap ? refs.y : refs.x, farc = swap ? refs.x : refs.y;
                 stack[sp * kBlock] = (uint32_t)farc;
                 sp++;
                 cur = nearc;
             } else if (h0) {
-                cur = r0;
+                cur = refs.x;
             } else if (h1) {
-                cur = r1;
+                cur = refs.y;
             } else {
                 if (sp == 0) return best;
                 sp--;
                 cur = (int32_t)stack[sp * kBlock];
             }
         }
-        // leaf
-        uint32_t enc = (uint32_t)~cur;
-        intersect_leaf<COUNT>(P.tris, enc >> 3, enc & 7u, o, d, cull, cw, best, n_tri);
+        uint32_t enc = (uint32_t)~cur;   // leaf
+        intersect_leaf<COUNT>(P.tris, enc >> 3, enc & 7u, o, d, cull, cw, best, tl);
         if (sp == 0) return best;
         sp--;
         cur = (int32_t)stack[sp * kBlock];
@@ -167,171 +211,457 @@ __device__ __forceinline__ float tone_map1(float x) {
     return q;
 }
 
-template <bool COUNT, bool AOV>
-__global__ __launch_bounds__(kBlock) void rt_render_kernel(const RenderParams P) {
-    extern __shared__ uint32_t lds_stack[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t tile = blockIdx.x * (kBlock / 64) + (tid >> 6);
-    const uint32_t tiles_total = P.tiles_x * P.local_bands;
-    unsigned n_rays = 0, n_node = 0, n_tri = 0, n_pf = 0;
+// One pixel-frame in flight on a lane.
+struct PixelState {
+    uint32_t x, local_row;      // where the result goes
+    float px, py;               // `pos` of main.wgsl:21
+    uint32_t seed;
+    uint32_t sample, bounce;
+    rt_v3 total;                // `color` of main.wgsl:25
+    rt_v3 light, color, pos, dir;
+    bool first_ray;
+};
 
-    // tile -> pixel.  Bands of 8 rows are dealt round-robin to shards
-    // (rt_abi.h rt_set_shard); pixel_idx stays global (main.wgsl:19).
+struct Camera {
+    rt_v3 cam, forward, right, up;
+    float Wf, Hf;
+};
+
+// sample(), main.wgsl:36-41: jitter (x drawn first), primary ray
+__device__ __forceinline__ void new_path(const RenderParams &P, const Camera &C, PixelState &S) {
+    float r0 = rt_rand(S.seed), r1 = rt_rand(S.seed);
+    float offx = (r0 * 2.0f - 1.0f) / C.Wf, offy = (r1 * 2.0f - 1.0f) / C.Hf;
+    float ux = (S.px + offx) * P.aspect * P.fov_scale;          // ray.wgsl:6-7
+    float uy = (S.py + offy) * P.fov_scale;
+    S.dir = rt_normalize((C.forward + C.right * ux) + C.up * uy);   // ray.wgsl:9
+    S.pos = C.cam;
+    S.light = v3(0.0f, 0.0f, 0.0f);
+    S.color = v3(1.0f, 1.0f, 1.0f);
+    S.bounce = 0;
+}
+
+// main.wgsl:17-25 for pixel (x, y)
+__device__ __forceinline__ void begin_pixel(const RenderParams &P, const Camera &C, PixelState &S, uint32_t x, uint32_t y,
+                                            uint32_t local_row) {
+    S.x = x;
+    S.local_row = local_row;
+    const uint32_t pixel_idx = y * P.width + x;
+    S.px = (float)x / C.Wf - 0.5f;                     // main.wgsl:20-21
+    S.py = (1.0f - (float)y / C.Hf) - 0.5f;
+    S.seed = rt_seed(pixel_idx, P.frame);              // main.wgsl:23
+    S.total = v3(0.0f, 0.0f, 0.0f);
+    S.sample = 0;
+    S.first_ray = true;
+    new_path(P, C, S);
+}
+
+// main.wgsl:27-32
+__device__ __forceinline__ void finish_pixel(const RenderParams &P, const PixelState &S) {
+    const float ns = (float)P.samples;
+    rt_v3 total = v3(S.total.x / ns, S.total.y / ns, S.total.z / ns);
+    rt_v3 mapped = v3(tone_map1(total.x * P.exposure), tone_map1(total.y * P.exposure), tone_map1(total.z * P.exposure));
+    const float w = 1.0f / (float)(P.accumulation_frame + 1u);
+    float4 *dst = reinterpret_cast<float4 *>(P.accum) + (size_t)S.local_row * P.width + S.x;
+    float4 old = *dst;
+    rt_v3 out = rt_mix(v3(old.x, old.y, old.z), mapped, w);
+    *dst = make_float4(out.x, out.y, out.z, old.w);
+}
+
+// Everything of sample()'s loop body after the trace (main.wgsl:46-69), plus the
+// sample bookkeeping of the flattened loops.  Returns true when the pixel-frame is complete.
+template <bool AOV>
+__device__ __forceinline__ bool shade(const RenderParams &P, const Camera &C, PixelState &S, const Hit &h) {
+    if (AOV && S.first_ray) {
+        uint32_t g = kNoHit, pr = kNoHit;
+        if (h.slot != kNoHit) { g = P.shade[h.slot].geometry; pr = P.shade[h.slot].primitive; }
+        uint2 *dst = reinterpret_cast<uint2 *>(P.aov) + (size_t)S.local_row * P.width + S.x;
+        *dst = make_uint2(g, pr);
+    }
+    S.first_ray = false;
+    bool path_done;
+    if (h.slot == kNoHit) {                                         // main.wgsl:46-50
+        float a = 0.5f * (S.dir.y + 1.0f);                          // misc.wgsl:1-4
+        float w = 1.0f - a;
+        rt_v3 bg = v3(w * 1.0f + a * 0.5f, w * 1.0f + a * 0.7f, w * 1.0f + a * 1.0f);
+        S.light = S.light + (bg * S.color) * P.environment;
+        path_done = true;
+    } else {
+        // attribute part of trace_ray, main.wgsl:86-101
+        const DevShade *sh = P.shade + h.slot;
+        float4 s0 = ld4(&sh->p0[0]), s1 = ld4(&sh->n0y), s2 = ld4(&sh->p1[0]), s3 = ld4(&sh->n1y),
+               s4 = ld4(&sh->p2[0]), s5 = ld4(&sh->n2y);
+        const uint32_t geometry = sh->geometry;
+        const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
+        rt_v3 normal = v3(s0.w * b0 + s2.w * b1 + s4.w * b2,
+                          s1.x * b0 + s3.x * b1 + s5.x * b2,
+                          s1.y * b0 + s3.y * b1 + s5.y * b2);
+        rt_v3 position = v3(s0.x * b0 + s2.x * b1 + s4.x * b2,
+                            s0.y * b0 + s2.y * b1 + s4.y * b2,
+                            s0.z * b0 + s2.z * b1 + s4.z * b2);
+        const DevMaterial *mp = P.materials + geometry;             // models[geometry_index].material
+        float4 m0 = ld4(&mp->diffuse[0]), m1 = ld4(&mp->specular[0]), m2 = ld4(&mp->emitted[0]);
+        const uint32_t tag = mp->tag;
+        if (tag == 0u) {                                            // main.wgsl:53-61
+            // get_scattered_direction_metal, ray.wgsl:12-32 (texture ids ignored: SURVEY §8 N3)
+            float is_specular = (rt_rand(S.seed) < m0.w) ? 1.0f : 0.0f;
+            float smoothness = 1.0f - m1.w;
+            rt_v3 diffuse = rand_cosine_hemisphere_vector(S.seed, normal);
+            rt_v3 specular = rt_reflect(S.dir, normal);
+            rt_v3 sdir = rt_mix(diffuse, specular, smoothness * is_specular);
+            rt_v3 scol = rt_mix(v3(m0.x, m0.y, m0.z), v3(m1.x, m1.y, m1.z), is_specular);
+            S.light = S.light + v3(m2.x, m2.y, m2.z) * S.color;
+            S.color = S.color * scol;
+            S.pos = position + normal * 0.0001f;
+            S.dir = sdir;
+        } else if (tag == 1u) {                                     // main.wgsl:62-68
+            // get_scattered_direction_dielectric, ray.wgsl:34-49
+            rt_v3 n = rt_dot(normal, S.dir) < 0.0f ? normal : -normal;   // faceForward(N, N, dir)
+            float ri = m2.w;
+            if (h.front) ri = 1.0f / m2.w;
+            float c = rt_dot(-S.dir, n);
+            float cos_theta = (c < 1.0f) ? c : 1.0f;
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            bool must_reflect = ri * sin_theta > 1.0f;
+            float reflect_prob = schlick_approximation(cos_theta, ri);
+            bool refl = must_reflect || (reflect_prob > rt_rand(S.seed));   // || short-circuits
+            rt_v3 next_dir = refl ? rt_reflect(S.dir, n) : rt_refract(S.dir, n, ri);
+            rt_v3 offset_dir = normal - (normal * 2.0f) * (h.front ? 1.0f : 0.0f);
+            S.pos = position + offset_dir * 0.0001f;
+            S.dir = next_dir;
+        }
+        S.bounce++;
+        path_done = S.bounce > P.max_bounces;                       // `bounce <= max_bounces`, main.wgsl:43
+    }
+    if (path_done) {
+        S.total = S.total + S.light;                                // main.wgsl:26
+        S.sample++;
+        if (S.sample >= P.samples) return true;
+        new_path(P, C, S);
+    }
+    return false;
+}
+
+template <bool COUNT, bool AOV>
+__device__ __forceinline__ bool step(const RenderParams &P, const Camera &C, uint32_t *stack, PixelState &S, Tally &tl) {
+    Hit h = trace<COUNT>(P, stack, S.pos, S.dir, tl);               // main.wgsl:44
+    tl.rays++;
+    return shade<AOV>(P, C, S, h);
+}
+
+__device__ __forceinline__ Camera load_camera(const RenderParams &P) {
+    Camera C;
+    C.cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    C.forward = v3(P.forward[0], P.forward[1], P.forward[2]);
+    C.right = v3(P.right[0], P.right[1], P.right[2]);
+    C.up = v3(P.up[0], P.up[1], P.up[2]);
+    C.Wf = (float)P.width;
+    C.Hf = (float)P.height;
+    return C;
+}
+
+// exact device-side counters: one atomic per wave per counter
+template <bool COUNT>
+__device__ __forceinline__ void flush_tally(const RenderParams &P, const Tally &tl) {
+    unsigned long long v[7] = {tl.rays, tl.pixel_frames, tl.nodes, tl.tris, tl.w_nodes, tl.w_leaf, tl.w_steps};
+    const int n = COUNT ? 7 : 2;
+    for (int k = 0; k < n; k++)
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+    if ((threadIdx.x & 63u) == 0) {
+        unsigned long long *dst = &P.counters->rays;
+        for (int k = 0; k < n; k++) atomicAdd(dst + k, v[k]);
+    }
+}
+
+// slot (shard-local pixel slot: tile-major, 64 slots per 8x8 tile) -> pixel.
+// Bands of 8 rows are dealt round-robin to shards (rt_abi.h rt_set_shard);
+// pixel_idx stays global (main.wgsl:19).
+__device__ __forceinline__ bool slot_to_pixel(const RenderParams &P, uint32_t slot, uint32_t &x, uint32_t &y, uint32_t &local_row) {
+    const uint32_t tile = slot >> 6, l = slot & 63u;
     const uint32_t band_local = tile / P.tiles_x;
     const uint32_t tx = tile - band_local * P.tiles_x;
-    const uint32_t x = tx * 8u + (lane & 7u);
-    const uint32_t y = (band_local * P.shard_count + P.shard_index) * 8u + (lane >> 3);
-    const bool active = tile < tiles_total && x < P.width && y < P.height;   // main.wgsl:17
+    x = tx * 8u + (l & 7u);
+    y = (band_local * P.shard_count + P.shard_index) * 8u + (l >> 3);
+    local_row = band_local * 8u + (l >> 3);
+    return x < P.width && y < P.height;                 // main.wgsl:17
+}
 
-    if (active) {
-        uint32_t *stack = lds_stack + tid;
-        const uint32_t pixel_idx = y * P.width + x;
-        const float Wf = (float)P.width, Hf = (float)P.height;
-        const float px = (float)x / Wf - 0.5f;                    // main.wgsl:20-21
-        const float py = (1.0f - (float)y / Hf) - 0.5f;
-        uint32_t seed = rt_seed(pixel_idx, P.frame);              // main.wgsl:23
-        const rt_v3 cam = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-        const rt_v3 forward = v3(P.forward[0], P.forward[1], P.forward[2]);
-        const rt_v3 right = v3(P.right[0], P.right[1], P.right[2]);
-        const rt_v3 up = v3(P.up[0], P.up[1], P.up[2]);
+// ---- variant 0: persistent wavefronts pulling pixel slots from a queue ----
+template <bool COUNT, bool AOV>
+__global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParams P) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total_slots = P.tiles_x * P.local_bands * 64u;
+    const Camera C = load_camera(P);
+    Tally tl;
+    PixelState S;
+    bool busy = false;
+    uint32_t w_next = 0, w_end = 0;   // the wave's claimed chunk [w_next, w_end), wave-uniform
+    bool drained = false;             // queue exhausted (wave-uniform)
 
-        rt_v3 total = v3(0.0f, 0.0f, 0.0f);     // `color` of main.wgsl:25
-        uint32_t sample = 0, bounce = 0;
-        rt_v3 light, color, pos, dir;
-        bool first_ray = true;
-
-        // sample(), main.wgsl:36-41: jitter (x drawn first), primary ray
-        auto new_path = [&]() {
-            float r0 = rt_rand(seed), r1 = rt_rand(seed);
-            float offx = (r0 * 2.0f - 1.0f) / Wf, offy = (r1 * 2.0f - 1.0f) / Hf;
-            float ux = (px + offx) * P.aspect * P.fov_scale;      // ray.wgsl:6-7
-            float uy = (py + offy) * P.fov_scale;
-            dir = rt_normalize((forward + right * ux) + up * uy); // ray.wgsl:9
-            pos = cam;
-            light = v3(0.0f, 0.0f, 0.0f);
-            color = v3(1.0f, 1.0f, 1.0f);
-            bounce = 0;
-        };
-
-        if (P.samples > 0) {
-            new_path();
-            for (;;) {
-                Hit h = trace<COUNT>(P, stack, pos, dir, n_node, n_tri);   // main.wgsl:44
-                n_rays++;
-                if (AOV && first_ray) {
-                    uint32_t g = kNoHit, pr = kNoHit;
-                    if (h.slot != kNoHit) { g = P.shade[h.slot].geometry; pr = P.shade[h.slot].primitive; }
-                    const uint32_t local_row = band_local * 8u + (lane >> 3);
-                    uint2 *dst = reinterpret_cast<uint2 *>(P.aov) + (size_t)local_row * P.width + x;
-                    *dst = make_uint2(g, pr);
-                }
-                first_ray = false;
-                bool path_done;
-                if (h.slot == kNoHit) {                                   // main.wgsl:46-50
-                    float a = 0.5f * (dir.y + 1.0f);                      // misc.wgsl:1-4
-                    float w = 1.0f - a;
-                    rt_v3 bg = v3(w * 1.0f + a * 0.5f, w * 1.0f + a * 0.7f, w * 1.0f + a * 1.0f);
-                    light = light + (bg * color) * P.environment;
-                    path_done = true;
-                } else {
-                    // attribute part of trace_ray, main.wgsl:86-101
-                    const DevShade *sh = P.shade + h.slot;
-                    float4 s0 = ld4(&sh->p0[0]), s1 = ld4(&sh->n0y), s2 = ld4(&sh->p1[0]), s3 = ld4(&sh->n1y),
-                           s4 = ld4(&sh->p2[0]), s5 = ld4(&sh->n2y);
-                    const uint32_t geometry = sh->geometry;
-                    const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
-                    rt_v3 normal = v3(s0.w * b0 + s2.w * b1 + s4.w * b2,
-                                      s1.x * b0 + s3.x * b1 + s5.x * b2,
-                                      s1.y * b0 + s3.y * b1 + s5.y * b2);
-                    rt_v3 position = v3(s0.x * b0 + s2.x * b1 + s4.x * b2,
-                                        s0.y * b0 + s2.y * b1 + s4.y * b2,
-                                        s0.z * b0 + s2.z * b1 + s4.z * b2);
-                    const DevMaterial *mp = P.materials + geometry;        // models[geometry_index].material
-                    float4 m0 = ld4(&mp->diffuse[0]), m1 = ld4(&mp->specular[0]), m2 = ld4(&mp->emitted[0]);
-                    const uint32_t tag = mp->tag;
-                    if (tag == 0u) {                                        // main.wgsl:53-61
-                        // get_scattered_direction_metal, ray.wgsl:12-32 (texture ids ignored: SURVEY §8 N3)
-                        float is_specular = (rt_rand(seed) < m0.w) ? 1.0f : 0.0f;
-                        float smoothness = 1.0f - m1.w;
-                        rt_v3 diffuse = rand_cosine_hemisphere_vector(seed, normal);
-                        rt_v3 specular = rt_reflect(dir, normal);
-                        rt_v3 sdir = rt_mix(diffuse, specular, smoothness * is_specular);
-                        rt_v3 scol = rt_mix(v3(m0.x, m0.y, m0.z), v3(m1.x, m1.y, m1.z), is_specular);
-                        light = light + v3(m2.x, m2.y, m2.z) * color;
-                        color = color * scol;
-                        pos = position + normal * 0.0001f;
-                        dir = sdir;
-                    } else if (tag == 1u) {                                 // main.wgsl:62-68
-                        // get_scattered_direction_dielectric, ray.wgsl:34-49
-                        rt_v3 n = rt_dot(normal, dir) < 0.0f ? normal : -normal;   // faceForward(N, N, dir)
-                        float ri = m2.w;
-                        if (h.front) ri = 1.0f / m2.w;
-                        float c = rt_dot(-dir, n);
-                        float cos_theta = (c < 1.0f) ? c : 1.0f;
-                        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-                        bool must_reflect = ri * sin_theta > 1.0f;
-                        float reflect_prob = schlick_approximation(cos_theta, ri);
-                        bool refl = must_reflect || (reflect_prob > rt_rand(seed));   // || short-circuits
-                        rt_v3 next_dir = refl ? rt_reflect(dir, n) : rt_refract(dir, n, ri);
-                        rt_v3 offset_dir = normal - (normal * 2.0f) * (h.front ? 1.0f : 0.0f);
-                        pos = position + offset_dir * 0.0001f;
-                        dir = next_dir;
-                    }
-                    bounce++;
-                    path_done = bounce > P.max_bounces;                     // `bounce <= max_bounces`, main.wgsl:43
-                }
-                if (path_done) {
-                    total = total + light;                                  // main.wgsl:26
-                    sample++;
-                    if (sample >= P.samples) break;
-                    new_path();
+    for (;;) {
+        unsigned long long idle = __ballot(!busy);
+        while (idle != 0ull) {
+            if (w_next == w_end) {
+                if (drained) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&P.queue->head, kChunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= total_slots) { drained = true; break; }
+                w_next = base;
+                w_end = min(base + kChunk, total_slots);
+            }
+            const uint32_t avail = w_end - w_next;
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            const uint32_t take = min(avail, n_idle);
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!busy && rank < take) {
+                uint32_t x, y, lr;
+                if (slot_to_pixel(P, w_next + rank, x, y, lr)) {
+                    begin_pixel(P, C, S, x, y, lr);
+                    busy = P.samples > 0;
+                    if (!busy) { S.total = v3(0.0f, 0.0f, 0.0f); finish_pixel(P, S); tl.pixel_frames++; }
                 }
             }
+            w_next += take;
+            idle = __ballot(!busy);
         }
-        // main.wgsl:27-32
-        const float ns = (float)P.samples;
-        total = v3(total.x / ns, total.y / ns, total.z / ns);
-        rt_v3 mapped = v3(tone_map1(total.x * P.exposure), tone_map1(total.y * P.exposure), tone_map1(total.z * P.exposure));
-        const float w = 1.0f / (float)(P.accumulation_frame + 1u);
-        const uint32_t local_row = band_local * 8u + (lane >> 3);
-        float4 *dst = reinterpret_cast<float4 *>(P.accum) + (size_t)local_row * P.width + x;
-        float4 old = *dst;
-        rt_v3 out = rt_mix(v3(old.x, old.y, old.z), mapped, w);
-        *dst = make_float4(out.x, out.y, out.z, old.w);
-        n_pf = 1;
+        if (__ballot(busy) == 0ull) break;
+        if (busy) {
+            if (COUNT && first_active_lane()) tl.w_steps++;
+            if (step<COUNT, AOV>(P, C, stack, S, tl)) {
+                finish_pixel(P, S);
+                tl.pixel_frames++;
+                busy = false;
+            }
+        }
     }
+    flush_tally<COUNT>(P, tl);
+}
 
-    // exact device-side counters: one atomic per wave per counter
-    unsigned long long r = n_rays, pf = n_pf, nn = n_node, nt = n_tri;
-    for (int off = 32; off > 0; off >>= 1) {
-        r += __shfl_down(r, off);
-        pf += __shfl_down(pf, off);
-        if (COUNT) { nn += __shfl_down(nn, off); nt += __shfl_down(nt, off); }
+// ---- variant 2: persistent wavefronts, lanes scheduled by phase ----
+// Ray lengths differ wildly inside a wave (a sky ray visits 3 nodes, a ray through
+// the teapot 80), so a wave that traces "one ray per lane" waits for its slowest
+// lane: measured lane utilization of the node loop in variant 0 is 15 %.  Here a
+// lane is a small state machine — FETCH (needs a pixel), NODE (at an inner node),
+// LEAF (has triangles to test), SHADE (trace finished) — and each loop iteration
+// the wave runs ONE phase body, the one most lanes are waiting for (ballot counts).
+// Lanes in other phases sit that iteration out; nobody waits for a whole ray.
+enum : uint32_t { PH_FETCH = 0, PH_NODE = 1, PH_LEAF = 2, PH_SHADE = 3, PH_DONE = 4 };
+
+template <bool COUNT, bool AOV>
+__global__ __launch_bounds__(kBlock) void rt_render_phased(const RenderParams P) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t total_slots = P.tiles_x * P.local_bands * 64u;
+    const Camera C = load_camera(P);
+    const bool cull = (P.flags & 1u) != 0;
+    const bool cw = P.front_face_cw != 0;
+    const DevNode *__restrict__ nodes = P.nodes;
+    Tally tl;
+    PixelState S;
+    Hit best;
+    // slab constants of the current ray (see make_slab): kept as scalars, not
+    // pairs, so the loop carries them in place
+    float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0, eps = 0;
+    uint32_t phase = PH_FETCH;
+    int32_t cur = 0;          // NODE: inner node index; LEAF: leaf reference (< 0)
+    uint32_t leaf_pos = 0;    // LEAF: triangles of the leaf already tested
+    int sp = 0;
+    uint32_t w_next = 0, w_end = 0;   // the wave's claimed chunk, wave-uniform
+    bool drained = false;
+    unsigned long long m_fetch = 0;
+    int c_fetch = 0;
+
+    auto start_trace = [&]() {        // rayQueryInitialize, main.wgsl:80
+        auto nz = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x; };
+        ix = __builtin_amdgcn_rcpf(nz(S.dir.x)); iy = __builtin_amdgcn_rcpf(nz(S.dir.y)); iz = __builtin_amdgcn_rcpf(nz(S.dir.z));
+        ox = -(S.pos.x * ix); oy = -(S.pos.y * iy); oz = -(S.pos.z * iz);
+        eps = 4.76837158e-7f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+        best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
+        cur = 0; sp = 0; leaf_pos = 0;
+        phase = PH_NODE;
+    };
+    // wave-uniform choice of the next phase body: the one most lanes wait for,
+    // weighted (P.tune) so cheap bodies run at lower occupancy than expensive ones
+    auto schedule = [&]() -> int {
+        m_fetch = drained ? 0ull : __ballot(phase == PH_FETCH);
+        c_fetch = __popcll(m_fetch);
+        const int c_node = __popcll(__ballot(phase == PH_NODE));
+        const int c_leaf = __popcll(__ballot(phase == PH_LEAF));
+        const int c_shade = __popcll(__ballot(phase == PH_SHADE));
+        if ((c_fetch | c_node | c_leaf | c_shade) == 0) return PH_DONE;
+        int pick = PH_NODE, best_c = c_node * P.tune[0];
+        if (c_leaf * P.tune[1] > best_c) { pick = PH_LEAF; best_c = c_leaf * P.tune[1]; }
+        if (c_shade * P.tune[2] > best_c) { pick = PH_SHADE; best_c = c_shade * P.tune[2]; }
+        if (c_fetch * P.tune[3] > best_c) { pick = PH_FETCH; }
+        return pick;
+    };
+
+    int pick = schedule();
+    while (pick != PH_DONE) {
+        if (pick == PH_NODE) {
+            do {
+                if (phase == PH_NODE) {
+                    if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
+                    const DevNode *n = nodes + cur;
+                    float4 a = ld4(&n->lo0x), b = ld4(&n->hi0y), c = ld4(&n->lo1z);
+                    int2 refs = *reinterpret_cast<const int2 *>(&n->ref0);
+                    float t0x = fmaf(a.x, ix, ox), t0y = fmaf(a.y, iy, oy), t0z = fmaf(a.z, iz, oz);
+                    float t1x = fmaf(a.w, ix, ox), t1y = fmaf(b.x, iy, oy), t1z = fmaf(b.y, iz, oz);
+                    float s0x = fmaf(b.z, ix, ox), s0y = fmaf(b.w, iy, oy), s0z = fmaf(c.x, iz, oz);
+                    float s1x = fmaf(c.y, ix, ox), s1y = fmaf(c.z, iy, oy), s1z = fmaf(c.w, iz, oz);
+                    float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
+                    float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
+                    float n1 = fmaxf(fmaxf(fminf(s0x, s1x), fminf(s0y, s1y)), fmaxf(fminf(s0z, s1z), kTMin));
+                    float f1 = fminf(fminf(fmaxf(s0x, s1x), fmaxf(s0y, s1y)), fminf(fmaxf(s0z, s1z), best.t));
+                    const bool h0 = n0 <= fmaf(f0, 1.000001f, eps);
+                    const bool h1 = n1 <= fmaf(f1, 1.000001f, eps);
+                    // next reference: the nearer hit child; the other one (if hit) is pushed
+                    const bool take1 = h1 & (!h0 | (n1 < n0));
+                    int32_t nxt = take1 ? refs.y : refs.x;
+                    if (h0 & h1) { stack[sp * kBlock] = (uint32_t)(take1 ? refs.x : refs.y); sp++; }
+                    if (!(h0 | h1)) {
+                        if (sp == 0) { phase = PH_SHADE; }
+                        else { sp--; nxt = (int32_t)stack[sp * kBlock]; }
+                    }
+                    cur = nxt;
+                    leaf_pos = 0;
+                    if (phase != PH_SHADE) phase = nxt >= 0 ? PH_NODE : PH_LEAF;
+                }
+                pick = schedule();
+            } while (pick == PH_NODE);
+        } else if (pick == PH_LEAF) {
+            do {
+                if (phase == PH_LEAF) {
+                    const uint32_t enc = (uint32_t)~cur;
+                    const uint32_t n_in_leaf = enc & 7u;
+                    if (leaf_pos < n_in_leaf) {
+                        if (COUNT) { tl.tris++; if (first_active_lane()) tl.w_leaf++; }
+                        intersect_tri(P.tris, (enc >> 3) + leaf_pos, S.pos, S.dir, cull, cw, best);
+                    }
+                    leaf_pos++;
+                    if (leaf_pos >= n_in_leaf) {
+                        if (sp == 0) { phase = PH_SHADE; }
+                        else {
+                            sp--;
+                            cur = (int32_t)stack[sp * kBlock];
+                            leaf_pos = 0;
+                            phase = cur >= 0 ? PH_NODE : PH_LEAF;
+                        }
+                    }
+                }
+                pick = schedule();
+            } while (pick == PH_LEAF);
+        } else if (pick == PH_SHADE) {
+            if (phase == PH_SHADE) {
+                if (COUNT && first_active_lane()) tl.w_steps++;
+                tl.rays++;
+                if (shade<AOV>(P, C, S, best)) {
+                    finish_pixel(P, S);
+                    tl.pixel_frames++;
+                    phase = PH_FETCH;
+                } else {
+                    start_trace();
+                }
+            }
+            pick = schedule();
+        } else {
+            // hand pixel slots of the wave's chunk to the lanes that need one
+            if (w_next == w_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&P.queue->head, kChunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (base >= total_slots) { drained = true; }
+                else { w_next = base; w_end = min(base + kChunk, total_slots); }
+            }
+            if (!drained) {
+                const uint32_t take = min(w_end - w_next, (uint32_t)c_fetch);
+                const uint32_t rank = (uint32_t)__popcll(m_fetch & ((1ull << lane) - 1ull));
+                if (phase == PH_FETCH && rank < take) {
+                    uint32_t x, y, lr;
+                    if (slot_to_pixel(P, w_next + rank, x, y, lr)) {
+                        begin_pixel(P, C, S, x, y, lr);
+                        if (P.samples > 0) { start_trace(); }
+                        else { S.total = v3(0.0f, 0.0f, 0.0f); finish_pixel(P, S); tl.pixel_frames++; }
+                    }
+                }
+                w_next += take;
+            }
+            pick = schedule();
+        }
     }
-    if (lane == 0) {
-        atomicAdd(&P.counters->rays, r);
-        atomicAdd(&P.counters->pixel_frames, pf);
-        if (COUNT) { atomicAdd(&P.counters->node_visits, nn); atomicAdd(&P.counters->triangle_tests, nt); }
+    flush_tally<COUNT>(P, tl);
+}
+
+// ---- variant 1: one wave per 8x8 tile (the reference's mapping) ----
+template <bool COUNT, bool AOV>
+__global__ __launch_bounds__(kBlock) void rt_render_tiles(const RenderParams P) {
+    extern __shared__ uint32_t lds_stack[];
+    uint32_t *stack = lds_stack + threadIdx.x;
+    const uint32_t tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t tiles_total = P.tiles_x * P.local_bands;
+    const Camera C = load_camera(P);
+    Tally tl;
+    uint32_t x, y, lr;
+    if (tile < tiles_total && slot_to_pixel(P, tile * 64u + (threadIdx.x & 63u), x, y, lr)) {
+        PixelState S;
+        begin_pixel(P, C, S, x, y, lr);
+        if (P.samples > 0) {
+            for (;;) {
+                if (COUNT && first_active_lane()) tl.w_steps++;
+                if (step<COUNT, AOV>(P, C, stack, S, tl)) break;
+            }
+        } else {
+            S.total = v3(0.0f, 0.0f, 0.0f);
+        }
+        finish_pixel(P, S);
+        tl.pixel_frames = 1;
     }
+    flush_tally<COUNT>(P, tl);
+}
+
+template <typename K>
+hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const RenderParams &P) {
+    hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, P);
+    return hipGetLastError();
 }
 
 }  // namespace
 
-// Host-side launcher.  Grid: one wave per 8x8 tile, 4 tiles per workgroup;
-// dynamic LDS = stack_entries x 256 lanes x 4 B.
-hipError_t rt_launch_render(const RenderParams &P, bool count, bool aov, hipStream_t stream) {
+// Persistent grid size: the number of 256-thread workgroups that are resident
+// at once (register/LDS limited), so every wave lives for the whole launch.
+int rt_persistent_blocks(int device, uint32_t stack_entries) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
+    int per_cu = 0;
+    const size_t lds = (size_t)stack_entries * kBlock * sizeof(uint32_t);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_persistent<false, false>, kBlock, lds) != hipSuccess || per_cu < 1)
+        per_cu = 4;
+    return per_cu * prop.multiProcessorCount;
+}
+
+// Host-side launcher.  Dynamic LDS = stack_entries x 256 lanes x 4 B.
+hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, int persistent_blocks, hipStream_t stream) {
     const uint32_t tiles = P.tiles_x * P.local_bands;
     if (tiles == 0) return hipSuccess;
-    const uint32_t blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
     const size_t lds = (size_t)P.stack_entries * kBlock * sizeof(uint32_t);
-    dim3 grid(blocks), block(kBlock);
-    if (count) {
-        if (aov) hipLaunchKernelGGL((rt_render_kernel<true, true>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((rt_render_kernel<true, false>), grid, block, lds, stream, P);
-    } else {
-        if (aov) hipLaunchKernelGGL((rt_render_kernel<false, true>), grid, block, lds, stream, P);
-        else hipLaunchKernelGGL((rt_render_kernel<false, false>), grid, block, lds, stream, P);
+    if (variant == 1) {
+        dim3 grid((tiles + (kBlock / 64) - 1) / (kBlock / 64));
+        if (count) return aov ? launch(rt_render_tiles<true, true>, grid, lds, stream, P) : launch(rt_render_tiles<true, false>, grid, lds, stream, P);
+        return aov ? launch(rt_render_tiles<false, true>, grid, lds, stream, P) : launch(rt_render_tiles<false, false>, grid, lds, stream, P);
     }
-    return hipGetLastError();
+    // no more waves than chunks of work
+    uint32_t chunks = (tiles * 64u + kChunk - 1) / kChunk;
+    uint32_t blocks = (uint32_t)persistent_blocks;
+    if (blocks > (chunks + 3) / 4) blocks = (chunks + 3) / 4;
+    if (blocks == 0) blocks = 1;
+    dim3 grid(blocks);
+    if (variant == 2) {
+        if (count) return aov ? launch(rt_render_phased<true, true>, grid, lds, stream, P) : launch(rt_render_phased<true, false>, grid, lds, stream, P);
+        return aov ? launch(rt_render_phased<false, true>, grid, lds, stream, P) : launch(rt_render_phased<false, false>, grid, lds, stream, P);
+    }
+    if (count) return aov ? launch(rt_render_persistent<true, true>, grid, lds, stream, P) : launch(rt_render_persistent<true, false>, grid, lds, stream, P);
+    return aov ? launch(rt_render_persistent<false, true>, grid, lds, stream, P) : launch(rt_render_persistent<false, false>, grid, lds, stream, P);
 }
