@@ -91,7 +91,7 @@ struct rt_context {
 
     bool opt_count = false, opt_aov = false, opt_cw = false;
     int opt_kernel = 2;
-    int32_t tune[8] = {4, 4, 2, 8, 0, 0, 0, 0};
+    int32_t tune[8] = {4, 4, 2, 4, 64, 0, 0, 0};
     bool timed = false;
 };
 
@@ -306,6 +306,7 @@ int launch(rt_context *ctx, const RtUniform &u) {
     P.counters = ctx->d_counters;
     P.width = u.window[0]; P.height = u.window[1];
     P.tiles_x = (P.width + 7u) / 8u;
+    P.inv_tiles_x = P.tiles_x ? 1.0f / (float)P.tiles_x : 0.0f;
     P.local_bands = ctx->local_bands;
     P.shard_index = ctx->shard_index; P.shard_count = ctx->shard_count;
     P.frame = u.frame; P.accumulation_frame = u.accumulation_frame; P.flags = u.flags;

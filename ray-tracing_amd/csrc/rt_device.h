@@ -83,6 +83,7 @@ struct RenderParams {
 
     uint32_t width, height;      // uniform.window
     uint32_t tiles_x;            // ceil(W / 8)
+    float inv_tiles_x;           // 1 / tiles_x (slot -> tile row without an integer division)
     uint32_t local_bands;        // 8-row bands this shard owns
     uint32_t shard_index, shard_count;
     uint32_t frame, accumulation_frame, flags;

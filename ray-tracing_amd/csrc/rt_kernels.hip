@@ -252,7 +252,6 @@ __device__ __forceinline__ void begin_pixel(const RenderParams &P, const Camera 
     S.total = v3(0.0f, 0.0f, 0.0f);
     S.sample = 0;
     S.first_ray = true;
-    new_path(P, C, S);
 }
 
 // main.wgsl:27-32
@@ -267,10 +266,10 @@ __device__ __forceinline__ void finish_pixel(const RenderParams &P, const PixelS
     *dst = make_float4(out.x, out.y, out.z, old.w);
 }
 
-// Everything of sample()'s loop body after the trace (main.wgsl:46-69), plus the
-// sample bookkeeping of the flattened loops.  Returns true when the pixel-frame is complete.
+// Everything of sample()'s loop body after the trace (main.wgsl:46-69).
+// Returns true when the path ended (miss, or the bounce budget is spent).
 template <bool AOV>
-__device__ __forceinline__ bool shade(const RenderParams &P, const Camera &C, PixelState &S, const Hit &h) {
+__device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S, const Hit &h) {
     if (AOV && S.first_ray) {
         uint32_t g = kNoHit, pr = kNoHit;
         if (h.slot != kNoHit) { g = P.shade[h.slot].geometry; pr = P.shade[h.slot].primitive; }
@@ -332,7 +331,14 @@ __device__ __forceinline__ bool shade(const RenderParams &P, const Camera &C, Pi
         S.bounce++;
         path_done = S.bounce > P.max_bounces;                       // `bounce <= max_bounces`, main.wgsl:43
     }
-    if (path_done) {
+    return path_done;
+}
+
+// shade_core plus the sample bookkeeping of the flattened loops.
+// Returns true when the pixel-frame is complete.
+template <bool AOV>
+__device__ __forceinline__ bool shade(const RenderParams &P, const Camera &C, PixelState &S, const Hit &h) {
+    if (shade_core<AOV>(P, S, h)) {
         S.total = S.total + S.light;                                // main.wgsl:26
         S.sample++;
         if (S.sample >= P.samples) return true;
@@ -377,7 +383,17 @@ __device__ __forceinline__ void flush_tally(const RenderParams &P, const Tally &
 // pixel_idx stays global (main.wgsl:19).
 __device__ __forceinline__ bool slot_to_pixel(const RenderParams &P, uint32_t slot, uint32_t &x, uint32_t &y, uint32_t &local_row) {
     const uint32_t tile = slot >> 6, l = slot & 63u;
-    const uint32_t band_local = tile / P.tiles_x;
+    // tile / tiles_x without the ~30-instruction u32 division: float quotient, corrected by +-1
+    // (exact for tile < 2^24; bigger images take the integer path)
+    uint32_t band_local;
+    if (tile < (1u << 24)) {
+        band_local = (uint32_t)((float)tile * P.inv_tiles_x);
+        int32_t r = (int32_t)(tile - band_local * P.tiles_x);
+        if (r < 0) band_local--;
+        else if (r >= (int32_t)P.tiles_x) band_local++;
+    } else {
+        band_local = tile / P.tiles_x;
+    }
     const uint32_t tx = tile - band_local * P.tiles_x;
     x = tx * 8u + (l & 7u);
     y = (band_local * P.shard_count + P.shard_index) * 8u + (l >> 3);
@@ -419,6 +435,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
                 uint32_t x, y, lr;
                 if (slot_to_pixel(P, w_next + rank, x, y, lr)) {
                     begin_pixel(P, C, S, x, y, lr);
+                    new_path(P, C, S);
                     busy = P.samples > 0;
                     if (!busy) { S.total = v3(0.0f, 0.0f, 0.0f); finish_pixel(P, S); tl.pixel_frames++; }
                 }
@@ -447,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 // LEAF (has triangles to test), SHADE (trace finished) — and each loop iteration
 // the wave runs ONE phase body, the one most lanes are waiting for (ballot counts).
 // Lanes in other phases sit that iteration out; nobody waits for a whole ray.
-enum : uint32_t { PH_FETCH = 0, PH_NODE = 1, PH_LEAF = 2, PH_SHADE = 3, PH_DONE = 4 };
+enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_NEXT = 3, PH_FETCH = 4, PH_DONE = 5 };
 
 template <bool COUNT, bool AOV>
 __global__ __launch_bounds__(kBlock) void rt_render_phased(const RenderParams P) {
@@ -465,7 +482,8 @@ __global__ __launch_bounds__(kBlock) void rt_render_phased(const RenderParams P)
     // slab constants of the current ray (see make_slab): kept as scalars, not
     // pairs, so the loop carries them in place
     float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0, eps = 0;
-    uint32_t phase = PH_FETCH;
+    int phase = PH_FETCH;
+    bool have_pixel = false;  // FETCH: a finished pixel-frame waits to be written out
     int32_t cur = 0;          // NODE: inner node index; LEAF: leaf reference (< 0)
     uint32_t leaf_pos = 0;    // LEAF: triangles of the leaf already tested
     int sp = 0;
@@ -486,16 +504,18 @@ __global__ __launch_bounds__(kBlock) void rt_render_phased(const RenderParams P)
     // wave-uniform choice of the next phase body: the one most lanes wait for,
     // weighted (P.tune) so cheap bodies run at lower occupancy than expensive ones
     auto schedule = [&]() -> int {
-        m_fetch = drained ? 0ull : __ballot(phase == PH_FETCH);
+        m_fetch = __ballot(phase == PH_FETCH);
         c_fetch = __popcll(m_fetch);
         const int c_node = __popcll(__ballot(phase == PH_NODE));
         const int c_leaf = __popcll(__ballot(phase == PH_LEAF));
         const int c_shade = __popcll(__ballot(phase == PH_SHADE));
-        if ((c_fetch | c_node | c_leaf | c_shade) == 0) return PH_DONE;
+        const int c_next = __popcll(__ballot(phase == PH_NEXT));
+        if ((c_fetch | c_node | c_leaf | c_shade | c_next) == 0) return PH_DONE;
         int pick = PH_NODE, best_c = c_node * P.tune[0];
         if (c_leaf * P.tune[1] > best_c) { pick = PH_LEAF; best_c = c_leaf * P.tune[1]; }
         if (c_shade * P.tune[2] > best_c) { pick = PH_SHADE; best_c = c_shade * P.tune[2]; }
-        if (c_fetch * P.tune[3] > best_c) { pick = PH_FETCH; }
+        if (c_next * P.tune[3] > best_c) { pick = PH_NEXT; best_c = c_next * P.tune[3]; }
+        if (c_fetch * P.tune[4] > best_c) { pick = PH_FETCH; }
         return pick;
     };
 
@@ -519,16 +539,17 @@ __global__ __launch_bounds__(kBlock) void rt_render_phased(const RenderParams P)
                     const bool h0 = n0 <= fmaf(f0, 1.000001f, eps);
                     const bool h1 = n1 <= fmaf(f1, 1.000001f, eps);
                     // next reference: the nearer hit child; the other one (if hit) is pushed
-                    const bool take1 = h1 & (!h0 | (n1 < n0));
+                    const bool take1 = h1 && (!h0 || n1 < n0);
                     int32_t nxt = take1 ? refs.y : refs.x;
-                    if (h0 & h1) { stack[sp * kBlock] = (uint32_t)(take1 ? refs.x : refs.y); sp++; }
-                    if (!(h0 | h1)) {
-                        if (sp == 0) { phase = PH_SHADE; }
+                    if (h0 && h1) { stack[sp * kBlock] = (uint32_t)(take1 ? refs.x : refs.y); sp++; }
+                    phase = PH_NODE;
+                    if (!h0 && !h1) {
+                        if (sp == 0) { phase = PH_SHADE; nxt = 0; }
                         else { sp--; nxt = (int32_t)stack[sp * kBlock]; }
                     }
                     cur = nxt;
                     leaf_pos = 0;
-                    if (phase != PH_SHADE) phase = nxt >= 0 ? PH_NODE : PH_LEAF;
+                    if (nxt < 0) phase = PH_LEAF;
                 }
                 pick = schedule();
             } while (pick == PH_NODE);
@@ -555,36 +576,56 @@ __global__ __launch_bounds__(kBlock) void rt_render_phased(const RenderParams P)
                 pick = schedule();
             } while (pick == PH_LEAF);
         } else if (pick == PH_SHADE) {
+            // hit or miss shading (main.wgsl:46-69); a path that ends moves on to NEXT or FETCH
             if (phase == PH_SHADE) {
                 if (COUNT && first_active_lane()) tl.w_steps++;
                 tl.rays++;
-                if (shade<AOV>(P, C, S, best)) {
-                    finish_pixel(P, S);
-                    tl.pixel_frames++;
-                    phase = PH_FETCH;
+                if (shade_core<AOV>(P, S, best)) {
+                    S.total = S.total + S.light;                    // main.wgsl:26
+                    S.sample++;
+                    if (S.sample >= P.samples) { phase = PH_FETCH; }
+                    else if (P.tune[5]) { phase = PH_NEXT; }
+                    else { new_path(P, C, S); start_trace(); }     // next sample, main.wgsl:36-41
                 } else {
                     start_trace();
                 }
             }
             pick = schedule();
+        } else if (pick == PH_NEXT) {
+            // next sample of the same pixel: sample(), main.wgsl:36-41
+            if (phase == PH_NEXT) {
+                new_path(P, C, S);
+                start_trace();
+            }
+            pick = schedule();
         } else {
-            // hand pixel slots of the wave's chunk to the lanes that need one
-            if (w_next == w_end) {
+            // pixel boundary: write out finished pixel-frames (main.wgsl:27-32), then hand
+            // pixel slots of the wave's chunk to the lanes
+            if (phase == PH_FETCH && have_pixel) {
+                finish_pixel(P, S);
+                tl.pixel_frames++;
+                have_pixel = false;
+            }
+            if (w_next == w_end && !drained) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&P.queue->head, kChunk);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base >= total_slots) { drained = true; }
                 else { w_next = base; w_end = min(base + kChunk, total_slots); }
             }
-            if (!drained) {
+            if (drained) {
+                if (phase == PH_FETCH) phase = PH_DONE;
+            } else {
                 const uint32_t take = min(w_end - w_next, (uint32_t)c_fetch);
                 const uint32_t rank = (uint32_t)__popcll(m_fetch & ((1ull << lane) - 1ull));
                 if (phase == PH_FETCH && rank < take) {
                     uint32_t x, y, lr;
                     if (slot_to_pixel(P, w_next + rank, x, y, lr)) {
                         begin_pixel(P, C, S, x, y, lr);
-                        if (P.samples > 0) { start_trace(); }
-                        else { S.total = v3(0.0f, 0.0f, 0.0f); finish_pixel(P, S); tl.pixel_frames++; }
+                        have_pixel = true;
+                        if (P.samples == 0) { S.total = v3(0.0f, 0.0f, 0.0f); }   // stays in FETCH: written out next round
+                        else if (P.tune[5]) { phase = PH_NEXT; }
+                        else { new_path(P, C, S); start_trace(); }
                     }
                 }
                 w_next += take;
@@ -608,6 +649,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_tiles(const RenderParams P) 
     if (tile < tiles_total && slot_to_pixel(P, tile * 64u + (threadIdx.x & 63u), x, y, lr)) {
         PixelState S;
         begin_pixel(P, C, S, x, y, lr);
+        new_path(P, C, S);
         if (P.samples > 0) {
             for (;;) {
                 if (COUNT && first_active_lane()) tl.w_steps++;

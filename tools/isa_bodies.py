@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Static instruction counts of the phased kernel's phase bodies (markers are injected into a temp copy)."""
+import re, subprocess, sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = open(os.path.join(ROOT, "ray-tracing_amd/csrc/rt_kernels.hip")).read()
+def mark(s, needle, name, after=True):
+    assert needle in s, needle
+    return s.replace(needle, (needle + f'\n asm volatile("; MARK {name}");') if after else (f' asm volatile("; MARK {name}");\n' + needle), 1)
+src = mark(src, "        if (pick == PH_NODE) {\n            do {", "node_begin")
+src = mark(src, "            } while (pick == PH_NODE);", "node_end")
+src = mark(src, "        } else if (pick == PH_LEAF) {\n            do {", "leaf_begin")
+src = mark(src, "            } while (pick == PH_LEAF);", "leaf_end")
+src = mark(src, "        } else if (pick == PH_SHADE) {", "shade_begin")
+src = mark(src, "            // pixel boundary: write out finished", "fetch_begin", after=False)
+src = mark(src, "        } else if (pick == PH_NEXT) {", "shade_end", after=False)
+os.makedirs("/tmp/isa", exist_ok=True)
+open("/tmp/isa/marked.hip", "w").write(src)
+subprocess.check_call(f"cp {ROOT}/ray-tracing_amd/csrc/rt_device.h {ROOT}/ray-tracing_amd/csrc/rt_math.h /tmp/isa/ && /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt --cuda-device-only -S /tmp/isa/marked.hip -o /tmp/isa/marked.s 2>/dev/null", shell=True)
+s = open("/tmp/isa/marked.s").read()
+m = re.search(r'(_ZN12_GLOBAL__N_116rt_render_phasedILb0ELb0EEEv12RenderParams:.*?\.end_amdhsa_kernel)', s, re.S)
+body = m.group(1).split('\n')
+marks = [(i, l.strip().split()[-1]) for i, l in enumerate(body) if 'MARK' in l]
+def count(a, b):
+    ls = [l.strip() for l in body[a:b] if l.strip() and not l.strip().startswith(('.', ';')) and not l.strip().endswith(':')]
+    v = sum(1 for l in ls if l.startswith('v_')); mv = sum(1 for l in ls if l.startswith('v_mov'))
+    return dict(total=len(ls), valu=v, vmov=mv, salu=sum(1 for l in ls if l.startswith('s_')), mem=sum(1 for l in ls if l.startswith(('global_', 'ds_'))))
+print(marks)
+for k in range(len(marks) - 1):
+    print(marks[k][1], '->', marks[k + 1][1], count(marks[k][0], marks[k + 1][0]))
+print('whole kernel', count(0, len(body)))
+if len(sys.argv) > 1:
+    a = [i for i, n in marks if n == sys.argv[1]][0]; b = [i for i, n in marks if n == sys.argv[2]][0]
+    for l in body[a:b + 1]:
+        if l.strip() and not l.strip().startswith(';') and 'implicit-def' not in l: print(l)
