@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C3")
-    ap.add_argument("--cpu-sample", default="960x540", help="resolution of the cpu_baseline sample frame")
+    ap.add_argument("--cpu-sample", default="3840x2160", help="resolution of the cpu_baseline sample frame")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -161,7 +161,7 @@ def main():
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "rt_render_kernel", "kernel_ms": kernel_ms,
+                               "kernel": "rt_render_phased", "kernel_ms": kernel_ms,
                                "bytes_per_ray": cpu["bytes_per_ray"], "nodes_per_ray": cpu["n_node"],
                                "tris_per_ray": cpu["n_tri"], "hit_fraction": cpu["hit"]}
         print(json.dumps(out), flush=True)

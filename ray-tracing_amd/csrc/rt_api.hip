@@ -239,6 +239,8 @@ int build_and_upload(rt_context *ctx) {
     }
     rt_host::Bvh2 bvh;
     rt_host::BvhBuildOptions opt;
+    if (ctx->tune[6] > 0) opt.max_leaf = (uint32_t)ctx->tune[6];
+    if (ctx->tune[7] > 0) opt.bins = (uint32_t)ctx->tune[7];
     rt_host::build_bvh2(boxes.data(), n_tris, opt, bvh);
     Repacked rp;
     repack(bvh, corners, ids, *ctx, rp);

@@ -12,13 +12,14 @@
 // are flattened into one loop of (trace, shade) steps, so a lane whose path
 // ended starts its next sample at once.
 //
-// Variant 0 (default) — persistent wavefronts with a work queue: the grid is
-//   sized to fill the chip once; each wave claims chunks of 256 pixel slots
-//   from a global head with one atomic, and hands slots to its lanes as they
-//   finish (ballot of idle lanes → prefix rank), so a lane that drew sky
-//   pixels keeps pulling work while its neighbours grind through 9-bounce paths.
+// Variant 2 (default) — persistent wavefronts, lanes scheduled by phase
+//   (rt_render_phased, see the comment above it).
+// Variant 0 — persistent wavefronts with a work queue, one whole ray per step:
+//   each wave claims chunks of 256 pixel slots from a global head with one
+//   atomic and hands slots to its lanes as they finish.
 // Variant 1 — one wave per 8x8 tile, one lane per pixel, the reference's own
-//   mapping (main.wgsl:15); kept for A/B measurements.
+//   mapping (main.wgsl:15).
+// Variants 0 and 1 are kept for A/B measurements (RT_OPT_KERNEL).
 //
 // Arithmetic follows the RTN-1 contract (rt_math.h): results are bit-identical
 // to oracle/rt_oracle.c.  Only the ray/box test is free to differ (it must be
@@ -32,6 +33,9 @@
 namespace {
 
 constexpr int kBlock = 256;                  // 4 waves per workgroup
+#ifndef RT_PHASED_WAVES
+#define RT_PHASED_WAVES 5                    // waves per SIMD the phased kernel is register-budgeted for
+#endif
 constexpr uint32_t kChunk = 256;             // pixel slots a wave claims per atomic (4 tiles)
 constexpr float kTMin = 0.001f;              // main.wgsl:77
 constexpr float kTMax = 3.40282347e+38f;     // main.wgsl:77
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_NEXT = 3, PH_FETCH = 4, PH_DONE = 5 };
 
 template <bool COUNT, bool AOV>
-__global__ __launch_bounds__(kBlock) void rt_render_phased(const RenderParams P) {
+__global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -675,11 +679,12 @@ hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const Ren
 // Persistent grid size: the number of 256-thread workgroups that are resident
 // at once (register/LDS limited), so every wave lives for the whole launch.
 int rt_persistent_blocks(int device, uint32_t stack_entries) {
+    // all persistent variants are launched with this grid; sized for the default (phased) kernel
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
     const size_t lds = (size_t)stack_entries * kBlock * sizeof(uint32_t);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_persistent<false, false>, kBlock, lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_phased<false, false>, kBlock, lds) != hipSuccess || per_cu < 1)
         per_cu = 4;
     return per_cu * prop.multiProcessorCount;
 }

@@ -13,12 +13,16 @@ ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--variants", default="0,1")
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--bvh", default="", help="max_leaf,bins builder options")
 ap.add_argument("--tune", default="", help="semicolon-separated weight sets for variant 2, e.g. 4,4,4,4;4,4,2,4")
 args = ap.parse_args()
 rt = graft.load_package()
 cfg = graft.load_config(args.config)
 W, H = int(cfg["width"] * args.scale), int(cfg["height"] * args.scale)
 ctx = rt.Context(0)
+if args.bvh:
+    ml, bins = (int(x) for x in args.bvh.split(","))
+    ctx.set_option(106, ml); ctx.set_option(107, bins)
 ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
 ctx.accum_resize(W, H)
 u = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], max_bounces=cfg["max_bounces"], samples=cfg["samples"],
