@@ -345,8 +345,6 @@ static inline int box_test(const ONode *n, v3 o, v3 inv, float tmin, float tbest
 
 static void nearest_bvh(const OScene *sc, v3 o, v3 d, float tmin, float tmax, int cull, OHit *best, OCounters *cnt) {
     best->t = tmax; best->id = O_NO_HIT;
-    /* spheres are not in the oracle's BVH: test them all (small counts only) */
-    for (uint64_t i = 0; i < sc->n_spheres; i++) consider_sphere(sc, i, o, d, tmin, best);
     if (sc->n_nodes == 0) return;
     v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     uint32_t stack[128];
@@ -359,8 +357,10 @@ static void nearest_bvh(const OScene *sc, v3 o, v3 d, float tmin, float tmax, in
         const ONode *n = &sc->nodes[stack[--sp]];
         if (n->count) {
             for (uint32_t i = 0; i < n->count; i++) {
+                uint32_t id = sc->order[n->left + i];   /* >= n_tris: a sphere */
                 cnt->triangle_tests++;
-                consider_tri(sc, sc->order[n->left + i], o, d, tmin, cull, best);
+                if (id < sc->n_tris) consider_tri(sc, id, o, d, tmin, cull, best);
+                else consider_sphere(sc, id - sc->n_tris, o, d, tmin, best);
             }
             continue;
         }
@@ -687,9 +687,20 @@ OScene *oracle_scene_create(const OVertex *vertices, uint64_t n_vertices,
             sc->tris[k].geometry = g; sc->tris[k].primitive = p;
         }
     }
-    if (build_bvh && nt > 0) {
-        OBox *boxes = (OBox *)malloc(sizeof(OBox) * nt);
-        sc->order = (uint32_t *)malloc(sizeof(uint32_t) * nt);
+    const uint64_t np = nt + n_spheres;   /* primitives: triangles, then spheres */
+    if (build_bvh && np > 0) {
+        OBox *boxes = (OBox *)malloc(sizeof(OBox) * np);
+        sc->order = (uint32_t *)malloc(sizeof(uint32_t) * np);
+        for (uint64_t i = 0; i < n_spheres; i++) {
+            /* padded a little: the quadratic's roots are not exact */
+            float r = spheres[i].radius * 1.0001f + 1e-6f;
+            for (int a = 0; a < 3; a++) {
+                boxes[nt + i].lo[a] = spheres[i].center[a] - r;
+                boxes[nt + i].hi[a] = spheres[i].center[a] + r;
+                boxes[nt + i].c[a] = spheres[i].center[a];
+            }
+            sc->order[nt + i] = (uint32_t)(nt + i);
+        }
         for (uint64_t i = 0; i < nt; i++) {
             const OTri *t = &sc->tris[i];
             const float *pa = &t->a.x, *pb = &t->b.x, *pc = &t->c.x;
@@ -700,10 +711,10 @@ OScene *oracle_scene_create(const OVertex *vertices, uint64_t n_vertices,
             }
             sc->order[i] = (uint32_t)i;
         }
-        sc->nodes = (ONode *)malloc(sizeof(ONode) * (2 * nt + 1));
+        sc->nodes = (ONode *)malloc(sizeof(ONode) * (2 * np + 1));
         sc->n_nodes = 1;
-        OBuild b = {sc, boxes, 2 * nt + 1};
-        build_rec(&b, 0, 0, (uint32_t)nt, 0);
+        OBuild b = {sc, boxes, 2 * np + 1};
+        build_rec(&b, 0, 0, (uint32_t)np, 0);
         free(boxes);
     }
     return sc;

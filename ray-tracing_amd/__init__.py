@@ -42,6 +42,11 @@ PRIMITIVE_DTYPE = np.dtype(
      "formats": [np.uint32, np.uint32, np.uint32, np.uint32, np.uint64],
      "offsets": [0, 4, 8, 12, 16], "itemsize": 24})
 
+SPHERE_DTYPE = np.dtype(
+    {"names": ["center", "radius", "model"],
+     "formats": [(np.float32, 3), np.float32, np.uint32],
+     "offsets": [0, 12, 16], "itemsize": 32})
+
 RT_OPT_COUNT_TRAVERSAL = 1
 RT_OPT_AOV = 2
 RT_OPT_KERNEL = 3
@@ -261,6 +266,11 @@ class Context:
         assert v.dtype.itemsize == 48 and p.dtype.itemsize == 24 and m.dtype.itemsize == 128
         _check(lib().rt_scene_upload(self.handle, v.ctypes.data, len(v), i.ctypes.data, len(i), p.ctypes.data, len(p),
                                      None if t is None else t.ctypes.data, m.ctypes.data, len(m)))
+
+    def spheres_upload(self, spheres):
+        sp = np.ascontiguousarray(spheres)
+        assert sp.dtype.itemsize == 32
+        _check(lib().rt_spheres_upload(self.handle, sp.ctypes.data, len(sp)))
 
     def scene_finish(self, host_scene: HostScene):
         _check(lib().rt_host_scene_finish(host_scene.handle, self.handle))

@@ -20,7 +20,7 @@
 #include "rt_device.h"
 #include "rt_math.h"
 
-hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, int persistent_blocks, hipStream_t stream);
+hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
 int rt_persistent_blocks(int device, uint32_t stack_entries);
 
 namespace {
@@ -63,6 +63,7 @@ struct rt_context {
     std::vector<RtGeometryPrimitive> primitives;
     std::vector<float> transforms;   // n_primitives x 12, row-major 3x4
     std::vector<RtGpuModel> models;
+    std::vector<RtSphere> spheres;   // build-defined primitive (BASELINE config C4)
 
     // device scene
     DevNode *d_nodes = nullptr;
@@ -140,15 +141,32 @@ void set_child(DevNode &n, int which, const rt_host::Aabb &box, int32_t ref) {
 
 void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const std::vector<uint32_t> &ids,
             const rt_context &ctx, Repacked &out) {
-    const uint64_t n_tris = bvh.order.size();
+    const uint64_t n_prims = bvh.order.size();     // triangles, then spheres
+    const uint64_t n_real_tris = ids.size() / 2;
+    const uint64_t n_tris = n_prims;
     out.tris.resize(n_tris ? n_tris : 1);
     out.shade.resize(n_tris ? n_tris : 1);
     memset(out.tris.data(), 0, out.tris.size() * sizeof(DevTri));
     memset(out.shade.data(), 0, out.shade.size() * sizeof(DevShade));
     for (uint64_t slot = 0; slot < n_tris; slot++) {
         const uint32_t gid = bvh.order[slot];
-        const float *c = &corners[9 * (size_t)gid];
         DevTri &t = out.tris[slot];
+        if (gid >= n_real_tris) {
+            const uint32_t si = (uint32_t)(gid - n_real_tris);
+            const RtSphere &sp = ctx.spheres[si];
+            t.ax = sp.center[0]; t.ay = sp.center[1]; t.az = sp.center[2];
+            t.e1x = sp.radius;
+            t.gid = gid;
+            t.is_sphere = 1;
+            DevShade &s = out.shade[slot];
+            memcpy(s.p0, sp.center, 12);
+            s.n0x = 1.0f / sp.radius;
+            s.geometry = 0x80000000u | si;
+            s.primitive = 0;
+            s.pad0 = sp.model;
+            continue;
+        }
+        const float *c = &corners[9 * (size_t)gid];
         t.ax = c[0]; t.ay = c[1]; t.az = c[2];
         t.e1x = c[3] - c[0]; t.e1y = c[4] - c[1]; t.e1z = c[5] - c[2];   // e1 = b - a
         t.e2x = c[6] - c[0]; t.e2y = c[7] - c[1]; t.e2z = c[8] - c[2];   // e2 = c - a
@@ -229,7 +247,9 @@ int build_and_upload(rt_context *ctx) {
             if ((uint64_t)m.vertex_start + ctx->indices[is + j] >= ctx->vertices.size())
                 return fail(RT_ERR_INVALID_ARGUMENT, "scene: model vertex range exceeds the vertex buffer");
     }
-    std::vector<rt_host::Aabb> boxes(n_tris);
+    const uint64_t n_prims = n_tris + ctx->spheres.size();
+    if (n_prims >= (1ull << 28)) return fail(RT_ERR_INVALID_ARGUMENT, "scene: more than 2^28 primitives");
+    std::vector<rt_host::Aabb> boxes(n_prims);
     for (uint64_t t = 0; t < n_tris; t++) {
         const float *c = &corners[9 * t];
         for (int k = 0; k < 3; k++) {
@@ -237,11 +257,18 @@ int build_and_upload(rt_context *ctx) {
             boxes[t].hi[k] = fmaxf(c[k], fmaxf(c[3 + k], c[6 + k]));
         }
     }
+    for (uint64_t i = 0; i < ctx->spheres.size(); i++) {
+        const RtSphere &sp = ctx->spheres[i];
+        if (!(sp.radius > 0.0f)) return fail(RT_ERR_INVALID_ARGUMENT, "sphere %llu: radius must be positive", (unsigned long long)i);
+        if (sp.model >= ctx->models.size()) return fail(RT_ERR_INVALID_ARGUMENT, "sphere %llu: model index out of range", (unsigned long long)i);
+        const float r = sp.radius * 1.0001f + 1e-6f;   // the quadratic's roots are not exact
+        for (int k = 0; k < 3; k++) { boxes[n_tris + i].lo[k] = sp.center[k] - r; boxes[n_tris + i].hi[k] = sp.center[k] + r; }
+    }
     rt_host::Bvh2 bvh;
     rt_host::BvhBuildOptions opt;
     if (ctx->tune[6] > 0) opt.max_leaf = (uint32_t)ctx->tune[6];
     if (ctx->tune[7] > 0) opt.bins = (uint32_t)ctx->tune[7];
-    rt_host::build_bvh2(boxes.data(), n_tris, opt, bvh);
+    rt_host::build_bvh2(boxes.data(), n_prims, opt, bvh);
     Repacked rp;
     repack(bvh, corners, ids, *ctx, rp);
     ctx->build_seconds = bvh.build_seconds;
@@ -272,7 +299,7 @@ int build_and_upload(rt_context *ctx) {
     RT_HIP(hipMemcpy(ctx->d_shade, rp.shade.data(), rp.shade.size() * sizeof(DevShade), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
     ctx->n_nodes = rp.nodes.size();
-    ctx->n_tris = n_tris;
+    ctx->n_tris = n_prims;
     ctx->stack_entries = rp.stack_entries;
     ctx->persistent_blocks = 0;
     ctx->have_scene = true;
@@ -338,7 +365,7 @@ int launch(rt_context *ctx, const RtUniform &u) {
         RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
         if (ctx->persistent_blocks == 0) ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries);
     }
-    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, ctx->persistent_blocks, ctx->stream));
+    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->spheres.empty(), ctx->persistent_blocks, ctx->stream));
     ctx->dispatches++;
     return RT_OK;
 }
@@ -438,15 +465,16 @@ int rt_scene_upload(rt_context *ctx, const RtVertex *vertices, uint64_t n_vertic
     ctx->models.assign(models, models + n_models);
     if (transforms) ctx->transforms.assign(transforms, transforms + 12ull * n_primitives);
     else ctx->transforms.clear();
+    ctx->spheres.clear();
     ctx->have_scene = false;
     return build_and_upload(ctx);
 }
 
 int rt_spheres_upload(rt_context *ctx, const RtSphere *spheres, uint64_t n_spheres) {
-    (void)spheres;
-    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
-    if (n_spheres == 0) return RT_OK;
-    return fail(RT_ERR_INVALID_ARGUMENT, "sphere primitives are not implemented yet (BASELINE config C4)");
+    if (!ctx || (n_spheres && !spheres)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_spheres_upload before rt_scene_upload");
+    ctx->spheres.assign(spheres, spheres + n_spheres);
+    return build_and_upload(ctx);
 }
 
 int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models, const float *transforms) {

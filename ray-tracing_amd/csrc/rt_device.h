@@ -38,7 +38,8 @@ static inline int32_t dev_leaf_ref(uint32_t first_slot, uint32_t count) {
 struct alignas(16) DevTri {
     float ax, ay, az, e1x;
     float e1y, e1z, e2x, e2y;
-    float e2z; uint32_t gid; uint32_t pad0, pad1;   // gid = triangle's place in index-buffer order (tie-break key)
+    float e2z; uint32_t gid; uint32_t is_sphere, pad1;   // gid = primitive's place in (index-buffer, then sphere) order: the tie-break key
+                                                     // sphere record: a = centre, e1x = radius, is_sphere = 1
 };
 static_assert(sizeof(DevTri) == 48, "DevTri");
 

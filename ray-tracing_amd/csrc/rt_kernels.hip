@@ -63,12 +63,30 @@ __device__ __forceinline__ bool first_active_lane() {
 
 // ray/triangle test of the contract (Moller-Trumbore, explicit fmaf); same
 // decisions as tri_test()/consider_tri() of the oracle, evaluated branch-free.
+// SPH builds also accept sphere records (build-defined primitive, SURVEY §8 A5;
+// oracle sphere_test()/consider_sphere()).
+template <bool SPH>
 __device__ __forceinline__ void intersect_tri(const DevTri *__restrict__ tris, uint32_t slot, rt_v3 o, rt_v3 d, bool cull,
                                               bool cw, Hit &best) {
     const DevTri *tp = tris + slot;
     float4 q0 = ld4(&tp->ax), q1 = ld4(&tp->e1y), q2 = ld4(&tp->e2z);
-    rt_v3 a = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
     uint32_t gid = __float_as_uint(q2.y);
+    if (SPH && __float_as_uint(q2.z) != 0u) {
+        const float kInf = __uint_as_float(0x7f800000u);
+        rt_v3 oc = o - v3(q0.x, q0.y, q0.z);
+        float r = q0.w;
+        float a = rt_dot_fma(d, d);
+        float hb = rt_dot_fma(oc, d);
+        float c = fmaf(-r, r, rt_dot_fma(oc, oc));
+        float disc = fmaf(hb, hb, -(a * c));
+        float sq = sqrtf(disc);
+        float t0 = (-hb - sq) / a, t1 = (-hb + sq) / a;
+        float t = (t0 > kTMin && t0 < kInf) ? t0 : t1;
+        bool ok = (disc >= 0.0f) & (t > kTMin) & (t < kInf) & ((t < best.t) | ((t == best.t) & (gid < best.gid)));
+        if (ok) { best.t = t; best.u = 0.0f; best.v = 0.0f; best.slot = slot; best.gid = gid; best.front = true; }
+        return;
+    }
+    rt_v3 a = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
     rt_v3 p = rt_cross_fma(d, e2);
     float det = rt_dot_fma(e1, p);
     float inv = 1.0f / det;
@@ -85,12 +103,12 @@ __device__ __forceinline__ void intersect_tri(const DevTri *__restrict__ tris, u
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, bool SPH>
 __device__ __forceinline__ void intersect_leaf(const DevTri *__restrict__ tris, uint32_t first, uint32_t count,
                                                rt_v3 o, rt_v3 d, bool cull, bool cw, Hit &best, Tally &tl) {
     for (uint32_t i = 0; i < count; i++) {
         if (COUNT) { tl.tris++; if (first_active_lane()) tl.w_leaf++; }
-        intersect_tri(tris, first + i, o, d, cull, cw, best);
+        intersect_tri<SPH>(tris, first + i, o, d, cull, cw, best);
     }
 }
 
@@ -132,7 +150,7 @@ __device__ __forceinline__ void test_node(const DevNode *n, const Slab &sl, floa
 }
 
 // nearest committed hit in (kTMin, kTMax): the ray query of main.wgsl:79-83
-template <bool COUNT>
+template <bool COUNT, bool SPH>
 __device__ __forceinline__ Hit trace(const RenderParams &P, uint32_t *__restrict__ stack, rt_v3 o, rt_v3 d, Tally &tl) {
     Hit best;
     best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
@@ -168,7 +186,7 @@ __device__ __forceinline__ Hit trace(const RenderParams &P, uint32_t *__restrict
             }
         }
         uint32_t enc = (uint32_t)~cur;   // leaf
-        intersect_leaf<COUNT>(P.tris, enc >> 3, enc & 7u, o, d, cull, cw, best, tl);
+        intersect_leaf<COUNT, SPH>(P.tris, enc >> 3, enc & 7u, o, d, cull, cw, best, tl);
         if (sp == 0) return best;
         sp--;
         cur = (int32_t)stack[sp * kBlock];
@@ -272,8 +290,9 @@ __device__ __forceinline__ void finish_pixel(const RenderParams &P, const PixelS
 
 // Everything of sample()'s loop body after the trace (main.wgsl:46-69).
 // Returns true when the path ended (miss, or the bounce budget is spent).
-template <bool AOV>
-__device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S, const Hit &h) {
+template <bool AOV, bool SPH>
+__device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S, const Hit &h_in) {
+    Hit h = h_in;
     if (AOV && S.first_ray) {
         uint32_t g = kNoHit, pr = kNoHit;
         if (h.slot != kNoHit) { g = P.shade[h.slot].geometry; pr = P.shade[h.slot].primitive; }
@@ -293,7 +312,7 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
         const DevShade *sh = P.shade + h.slot;
         float4 s0 = ld4(&sh->p0[0]), s1 = ld4(&sh->n0y), s2 = ld4(&sh->p1[0]), s3 = ld4(&sh->n1y),
                s4 = ld4(&sh->p2[0]), s5 = ld4(&sh->n2y);
-        const uint32_t geometry = sh->geometry;
+        uint32_t geometry = sh->geometry;
         const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
         rt_v3 normal = v3(s0.w * b0 + s2.w * b1 + s4.w * b2,
                           s1.x * b0 + s3.x * b1 + s5.x * b2,
@@ -301,6 +320,14 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
         rt_v3 position = v3(s0.x * b0 + s2.x * b1 + s4.x * b2,
                             s0.y * b0 + s2.y * b1 + s4.y * b2,
                             s0.z * b0 + s2.z * b1 + s4.z * b2);
+        if (SPH && (geometry & 0x80000000u)) {
+            // sphere: P = o + t d, N = (P - C) / r, front = dot(d, N) < 0; the record
+            // holds C in p0, 1/r in n0x and the model index in pad0
+            position = S.pos + S.dir * h.t;
+            normal = (position - v3(s0.x, s0.y, s0.z)) * s0.w;
+            h.front = rt_dot(S.dir, normal) < 0.0f;
+            geometry = sh->pad0;
+        }
         const DevMaterial *mp = P.materials + geometry;             // models[geometry_index].material
         float4 m0 = ld4(&mp->diffuse[0]), m1 = ld4(&mp->specular[0]), m2 = ld4(&mp->emitted[0]);
         const uint32_t tag = mp->tag;
@@ -340,9 +367,9 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
 
 // shade_core plus the sample bookkeeping of the flattened loops.
 // Returns true when the pixel-frame is complete.
-template <bool AOV>
+template <bool AOV, bool SPH>
 __device__ __forceinline__ bool shade(const RenderParams &P, const Camera &C, PixelState &S, const Hit &h) {
-    if (shade_core<AOV>(P, S, h)) {
+    if (shade_core<AOV, SPH>(P, S, h)) {
         S.total = S.total + S.light;                                // main.wgsl:26
         S.sample++;
         if (S.sample >= P.samples) return true;
@@ -351,11 +378,11 @@ __device__ __forceinline__ bool shade(const RenderParams &P, const Camera &C, Pi
     return false;
 }
 
-template <bool COUNT, bool AOV>
+template <bool COUNT, bool AOV, bool SPH>
 __device__ __forceinline__ bool step(const RenderParams &P, const Camera &C, uint32_t *stack, PixelState &S, Tally &tl) {
-    Hit h = trace<COUNT>(P, stack, S.pos, S.dir, tl);               // main.wgsl:44
+    Hit h = trace<COUNT, SPH>(P, stack, S.pos, S.dir, tl);          // main.wgsl:44
     tl.rays++;
-    return shade<AOV>(P, C, S, h);
+    return shade<AOV, SPH>(P, C, S, h);
 }
 
 __device__ __forceinline__ Camera load_camera(const RenderParams &P) {
@@ -406,7 +433,7 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderParams &P, uint32_t sl
 }
 
 // ---- variant 0: persistent wavefronts pulling pixel slots from a queue ----
-template <bool COUNT, bool AOV>
+template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -450,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
         if (__ballot(busy) == 0ull) break;
         if (busy) {
             if (COUNT && first_active_lane()) tl.w_steps++;
-            if (step<COUNT, AOV>(P, C, stack, S, tl)) {
+            if (step<COUNT, AOV, SPH>(P, C, stack, S, tl)) {
                 finish_pixel(P, S);
                 tl.pixel_frames++;
                 busy = false;
@@ -470,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 // Lanes in other phases sit that iteration out; nobody waits for a whole ray.
 enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_NEXT = 3, PH_FETCH = 4, PH_DONE = 5 };
 
-template <bool COUNT, bool AOV>
+template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -564,7 +591,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                     const uint32_t n_in_leaf = enc & 7u;
                     if (leaf_pos < n_in_leaf) {
                         if (COUNT) { tl.tris++; if (first_active_lane()) tl.w_leaf++; }
-                        intersect_tri(P.tris, (enc >> 3) + leaf_pos, S.pos, S.dir, cull, cw, best);
+                        intersect_tri<SPH>(P.tris, (enc >> 3) + leaf_pos, S.pos, S.dir, cull, cw, best);
                     }
                     leaf_pos++;
                     if (leaf_pos >= n_in_leaf) {
@@ -584,7 +611,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
             if (phase == PH_SHADE) {
                 if (COUNT && first_active_lane()) tl.w_steps++;
                 tl.rays++;
-                if (shade_core<AOV>(P, S, best)) {
+                if (shade_core<AOV, SPH>(P, S, best)) {
                     S.total = S.total + S.light;                    // main.wgsl:26
                     S.sample++;
                     if (S.sample >= P.samples) { phase = PH_FETCH; }
@@ -641,7 +668,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
 }
 
 // ---- variant 1: one wave per 8x8 tile (the reference's mapping) ----
-template <bool COUNT, bool AOV>
+template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock) void rt_render_tiles(const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -657,7 +684,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_tiles(const RenderParams P) 
         if (P.samples > 0) {
             for (;;) {
                 if (COUNT && first_active_lane()) tl.w_steps++;
-                if (step<COUNT, AOV>(P, C, stack, S, tl)) break;
+                if (step<COUNT, AOV, SPH>(P, C, stack, S, tl)) break;
             }
         } else {
             S.total = v3(0.0f, 0.0f, 0.0f);
@@ -684,31 +711,39 @@ int rt_persistent_blocks(int device, uint32_t stack_entries) {
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
     const size_t lds = (size_t)stack_entries * kBlock * sizeof(uint32_t);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_phased<false, false>, kBlock, lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_phased<false, false, false>, kBlock, lds) != hipSuccess || per_cu < 1)
         per_cu = 4;
     return per_cu * prop.multiProcessorCount;
 }
 
 // Host-side launcher.  Dynamic LDS = stack_entries x 256 lanes x 4 B.
-hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, int persistent_blocks, hipStream_t stream) {
+template <bool COUNT, bool AOV, bool SPH>
+static hipError_t launch_variant(const RenderParams &P, int variant, dim3 tile_grid, dim3 persistent_grid, size_t lds, hipStream_t stream) {
+    if (variant == 1) return launch(rt_render_tiles<COUNT, AOV, SPH>, tile_grid, lds, stream, P);
+    if (variant == 0) return launch(rt_render_persistent<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
+    return launch(rt_render_phased<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
+}
+
+hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream) {
     const uint32_t tiles = P.tiles_x * P.local_bands;
     if (tiles == 0) return hipSuccess;
     const size_t lds = (size_t)P.stack_entries * kBlock * sizeof(uint32_t);
-    if (variant == 1) {
-        dim3 grid((tiles + (kBlock / 64) - 1) / (kBlock / 64));
-        if (count) return aov ? launch(rt_render_tiles<true, true>, grid, lds, stream, P) : launch(rt_render_tiles<true, false>, grid, lds, stream, P);
-        return aov ? launch(rt_render_tiles<false, true>, grid, lds, stream, P) : launch(rt_render_tiles<false, false>, grid, lds, stream, P);
-    }
-    // no more waves than chunks of work
+    dim3 tile_grid((tiles + (kBlock / 64) - 1) / (kBlock / 64));
+    // persistent grids: no more waves than chunks of work
     uint32_t chunks = (tiles * 64u + kChunk - 1) / kChunk;
     uint32_t blocks = (uint32_t)persistent_blocks;
     if (blocks > (chunks + 3) / 4) blocks = (chunks + 3) / 4;
     if (blocks == 0) blocks = 1;
-    dim3 grid(blocks);
-    if (variant == 2) {
-        if (count) return aov ? launch(rt_render_phased<true, true>, grid, lds, stream, P) : launch(rt_render_phased<true, false>, grid, lds, stream, P);
-        return aov ? launch(rt_render_phased<false, true>, grid, lds, stream, P) : launch(rt_render_phased<false, false>, grid, lds, stream, P);
+    dim3 pgrid(blocks);
+    const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
+    switch (sel) {
+        case 0: return launch_variant<false, false, false>(P, variant, tile_grid, pgrid, lds, stream);
+        case 1: return launch_variant<false, false, true>(P, variant, tile_grid, pgrid, lds, stream);
+        case 2: return launch_variant<false, true, false>(P, variant, tile_grid, pgrid, lds, stream);
+        case 3: return launch_variant<false, true, true>(P, variant, tile_grid, pgrid, lds, stream);
+        case 4: return launch_variant<true, false, false>(P, variant, tile_grid, pgrid, lds, stream);
+        case 5: return launch_variant<true, false, true>(P, variant, tile_grid, pgrid, lds, stream);
+        case 6: return launch_variant<true, true, false>(P, variant, tile_grid, pgrid, lds, stream);
+        default: return launch_variant<true, true, true>(P, variant, tile_grid, pgrid, lds, stream);
     }
-    if (count) return aov ? launch(rt_render_persistent<true, true>, grid, lds, stream, P) : launch(rt_render_persistent<true, false>, grid, lds, stream, P);
-    return aov ? launch(rt_render_persistent<false, true>, grid, lds, stream, P) : launch(rt_render_persistent<false, false>, grid, lds, stream, P);
 }

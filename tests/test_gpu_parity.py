@@ -159,6 +159,63 @@ def test_geometry_transforms(rt, oracle_mod, scenes):
         assert_images_identical(ctx.accum_download(), want, "transforms")
 
 
+def test_spheres(rt, oracle_mod, obj_loader, scenes):
+    """Build-defined sphere primitives (BASELINE config C4, SURVEY §8 A5): mixed with triangles in one BVH;
+    metal and dielectric spheres; parity is HIP vs the oracle only (the reference has no spheres)."""
+    cfg = config("C2")
+    w, h = 112, 63
+    s = scenes("teapot")
+    models = s.models.copy()
+    models["tag"][2] = 1
+    models["refractive_index"][2] = 1.4
+    import copy
+    s2 = copy.copy(s)
+    s2.models = models
+    rng = np.random.default_rng(3)
+    sp = np.zeros(60, obj_loader.SPHERE_DTYPE)
+    sp["center"] = rng.uniform([-1.5, 0.0, -1.5], [1.5, 1.5, 1.5], (60, 3)).astype(np.float32)
+    sp["radius"] = rng.uniform(0.05, 0.3, 60).astype(np.float32)
+    sp["model"] = rng.integers(0, len(models), 60)
+    osc = oracle_mod.OracleScene(s2, spheres=sp)
+    want, want_hits, cnt = osc.render(uniforms_for(oracle_mod, cfg, w, h, samples=3), mode=0, want_hits=True)
+    assert (want_hits[..., 0] >= 0x80000000).sum() > 100       # spheres are visible
+    with rt.Context(0) as ctx:
+        ctx.scene_upload(s.vertices, s.indices, s.primitives, models)
+        ctx.spheres_upload(sp)
+        ctx.set_option(rt.RT_OPT_AOV, 1)
+        for variant in (2, 0, 1):
+            ctx.set_option(rt.RT_OPT_KERNEL, variant)
+            ctx.accum_resize(w, h)
+            ctx.stats_reset()
+            ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=3))
+            assert ctx.stats().rays == cnt.rays
+            assert np.array_equal(ctx.aov_download(), want_hits)
+            assert_images_identical(ctx.accum_download(), want, f"spheres, kernel variant {variant}")
+        bad = sp.copy()
+        bad["radius"][3] = 0.0
+        with pytest.raises(rt.RtError):
+            ctx.spheres_upload(bad)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_kernel_variants_agree(rt, oracle_mod, oracle_scenes, ctxs, variant):
+    """The A/B kernel variants (RT_OPT_KERNEL 0: persistent per-ray, 1: tile per wave) produce the same bits."""
+    cfg = config("C3")
+    w, h = 136, 77
+    ctx = ctxs("teapot-circle")
+    ctx.set_option(rt.RT_OPT_KERNEL, variant)
+    try:
+        ctx.accum_resize(w, h)
+        ctx.stats_reset()
+        ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=3))
+        got, hits, st = ctx.accum_download(), ctx.aov_download(), ctx.stats()
+    finally:
+        ctx.set_option(rt.RT_OPT_KERNEL, 2)
+    want, want_hits, cnt = oracle_scenes("teapot-circle").render(uniforms_for(oracle_mod, cfg, w, h, samples=3), mode=1, want_hits=True)
+    assert st.rays == cnt.rays and np.array_equal(hits, want_hits)
+    assert_images_identical(got, want, f"variant {variant}")
+
+
 @pytest.mark.parametrize("world,w,h", [(2, 72, 52), (3, 40, 64), (8, 64, 20)])
 def test_shards_tile_the_unsharded_image(rt, ctxs, world, w, h):
     """rt_set_shard: the union of the shards' packed bands is bit-identical to the 1-shard image."""
