@@ -34,7 +34,13 @@ def cpu_baseline_and_byte_model(cfg, sample_w, sample_h):
     """Oracle (BVH mode, OpenMP) on a reduced-resolution frame of the same
     scene/camera/spp: gives the CPU Mrays/s and the per-ray node/triangle means."""
     from oracle import obj_loader, oracle
-    sc = oracle.OracleScene(obj_loader.load(os.path.join(ROOT, cfg["scene"])))
+    if cfg["scene"].startswith("synth:"):
+        synth = __import__("ray_tracing_amd.synth", fromlist=["x"])
+        s = synth.load_config_scene(cfg, ROOT)
+        sc = oracle.OracleScene(obj_loader.Scene(s.vertices, s.indices, s.primitives, s.models),
+                                spheres=s.spheres if len(s.spheres) else None)
+    else:
+        sc = oracle.OracleScene(obj_loader.load(os.path.join(ROOT, cfg["scene"])))
     u = oracle.make_uniform(sample_w, sample_h, cfg["position"], cfg["yaw"], cfg["pitch"],
                             aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]),
                             max_bounces=cfg["max_bounces"], samples=cfg["samples"])
@@ -81,9 +87,16 @@ def main():
     cfg = graft.load_config(args.config)
     W, H = cfg["width"], cfg["height"]
 
-    hs = rt.HostScene(os.path.join(ROOT, cfg["scene"]))
     ctx = rt.Context(local_rank)
-    ctx.scene_finish(hs)
+    if cfg["scene"].startswith("synth:"):
+        synth = __import__("ray_tracing_amd.synth", fromlist=["x"])
+        syn = synth.load_config_scene(cfg, ROOT)
+        ctx.scene_upload(syn.vertices, syn.indices, syn.primitives, syn.models)
+        if len(syn.spheres):
+            ctx.spheres_upload(syn.spheres)
+        del syn
+    else:
+        ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_shard(rank, world)
@@ -140,10 +153,10 @@ def main():
         assert pixel_frames == W * H * args.steps, (pixel_frames, W * H * args.steps)
         assert img is not None and bool(torch.isfinite(img[..., :3]).all())
         out = {
-            "metric": "Mrays/s (node) teapot-circle 4K 8-bounce; % of HBM roofline",
+            "metric": "Mrays/s (node) teapot-circle 4K 8-bounce; % of HBM roofline" if args.config == "C3" else f"Mrays/s (node) config {args.config}",
             "value": rays / dt / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic camera on the reference's scenes/teapot-circle.obj",
+            "vs_baseline": None, "dtype": "f32", "data": f"synthetic camera on {cfg['scene']}",
             "config": {"workload": f"{args.config}: {os.path.basename(cfg['scene'])} {W}x{H}, {cfg['samples']} spp/step x {args.steps} steps, "
                                    f"{cfg['max_bounces']} bounces, 8-row bands round-robin over {world} GPU(s), one framebuffer gather",
                        "rays": rays, "spp": cfg["samples"] * args.steps,

@@ -197,6 +197,28 @@ def test_spheres(rt, oracle_mod, obj_loader, scenes):
             ctx.spheres_upload(bad)
 
 
+def test_synthetic_lattice_scene(rt, oracle_mod, obj_loader):
+    """Small instance of the C4 generator (baked teapot lattice + spheres): deeper BVH, incoherent bounces."""
+    import __graft_entry__ as graft
+    graft.load_package()
+    from ray_tracing_amd import synth
+    s = synth.lattice_scene(scene_path("teapot"), 26, 300, seed=1)
+    w, h = 96, 54
+    cam = s.camera
+    ou = oracle_mod.make_uniform(w, h, cam["position"], cam["yaw"], cam["pitch"], max_bounces=8, samples=4)
+    osc = oracle_mod.OracleScene(obj_loader.Scene(s.vertices, s.indices, s.primitives, s.models), spheres=s.spheres)
+    want, want_hits, cnt = osc.render(ou, mode=1, want_hits=True)
+    with rt.Context(0) as ctx:
+        ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+        ctx.spheres_upload(s.spheres)
+        ctx.set_option(rt.RT_OPT_AOV, 1)
+        ctx.accum_resize(w, h)
+        ctx.dispatch(rt.make_uniform(w, h, cam["position"], cam["yaw"], cam["pitch"], max_bounces=8, samples=4))
+        assert ctx.stats().rays == cnt.rays
+        assert np.array_equal(ctx.aov_download(), want_hits)
+        assert_images_identical(ctx.accum_download(), want, "synthetic lattice")
+
+
 @pytest.mark.parametrize("variant", [0, 1])
 def test_kernel_variants_agree(rt, oracle_mod, oracle_scenes, ctxs, variant):
     """The A/B kernel variants (RT_OPT_KERNEL 0: persistent per-ray, 1: tile per wave) produce the same bits."""
