@@ -1,12 +1,14 @@
 #!/bin/bash
 # Profile recipe for the headline bench (run on the GPU box through gpurun).
-# Usage: bash profiles/run_profile.sh <tag>     → gpurun_out/prof_<tag>/
+# Usage: bash profiles/run_profile.sh <tag> [config] [steps]    → gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r1}
+CONFIG=${2:-C3}
+STEPS=${3:-4}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 4 --warmup 1 --no-cpu"
+CMD="python3 bench.py --config $CONFIG --steps $STEPS --warmup 1 --no-cpu"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" \
             "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_INSTS_VMEM_RD" \
