@@ -33,6 +33,9 @@
 namespace {
 
 constexpr int kBlock = 256;                  // 4 waves per workgroup
+#ifndef RT_NODE_REPS
+#define RT_NODE_REPS 3                       // node steps per scheduling decision
+#endif
 #ifndef RT_PHASED_WAVES
 #define RT_PHASED_WAVES 5                    // waves per SIMD the phased kernel is register-budgeted for
 #endif
@@ -554,6 +557,8 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     while (pick != PH_DONE) {
         if (pick == PH_NODE) {
             do {
+#pragma unroll
+              for (int rep = 0; rep < RT_NODE_REPS; rep++)
                 if (phase == PH_NODE) {
                     if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
                     const DevNode *n = nodes + cur;
