@@ -172,8 +172,14 @@ def main():
             rays_per_launch = rays / args.steps / world       # per GPU, per launch
             algo_bytes = rays_per_launch * cpu["bytes_per_ray"] + (W * H / world) * S_FB
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE x2 on gfx950 +
+            # WRITE_SIZE, MI355X_MICROARCH.md §HBM), recorded by tools/pmc_summary.py; null if never profiled
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath) and world == 1:
+                traffic = json.load(open(tpath)).get(args.config, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                                "kernel": "rt_render_phased", "kernel_ms": kernel_ms,
                                "bytes_per_ray": cpu["bytes_per_ray"], "nodes_per_ray": cpu["n_node"],
                                "tris_per_ray": cpu["n_tri"], "hit_fraction": cpu["hit"]}

@@ -353,3 +353,31 @@ def test_full_size_c3_frame_properties(rt, ctxs):
     ctx.dispatch(u2)
     again = ctx.accum_download()
     assert np.abs(again - img).max() <= 6e-8
+
+
+def test_headless_cli_capture_matches_oracle(rt, oracle_mod, oracle_scenes, tmp_path):
+    """rt_cli = the reference's frame loop (src/app.rs:74-102) + Capture (src/ui.rs:78-94), headless: its PNG
+    must hold exactly the oracle's accumulation buffer pushed through `(x*255) as u8`."""
+    import struct
+    import subprocess
+    import zlib
+    cfg = config("C1")
+    w, h, spp, frames = 40, 24, 3, 2
+    out = str(tmp_path / "cli.png")
+    exe = os.path.join(ROOT, "ray-tracing_amd", "rt_cli")
+    pos = ",".join(str(v) for v in cfg["position"])
+    r = subprocess.run([exe, "--scene", scene_path("cornell-box"), "--size", f"{w}x{h}", "--samples", str(spp), "--frames", str(frames),
+                        "--bounces", str(cfg["max_bounces"]), "--pos", pos, "--yaw", repr(cfg["yaw"]), "--pitch", "0", "--out", out],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    accum, _ = oracle_scenes("cornell-box").render_frames(uniforms_for(oracle_mod, cfg, w, h, samples=spp), frames, mode=1)
+    want = oracle_mod.capture_rgb8(accum).reshape(h, w, 3)
+    data = open(out, "rb").read()
+    pos_, idat = 8, b""
+    while pos_ < len(data):
+        n, typ = struct.unpack(">I4s", data[pos_:pos_ + 8])
+        if typ == b"IDAT":
+            idat += data[pos_ + 8:pos_ + 8 + n]
+        pos_ += 12 + n
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert np.array_equal(rows[:, 1:].reshape(h, w, 3), want)

@@ -178,3 +178,15 @@ def test_default_uniform(rt):
     assert tuple(u["position"][0]) == (1.0, 1.0, 1.0) and u["fov"][0] == np.float32(np.pi / 2)
     assert u["frame"][0] == 0 and u["accumulation_frame"][0] == 1 and u["max_bounces"][0] == 10
     assert u["samples"][0] == 5 and u["exposure"][0] == 1.0 and u["environment"][0] == 1.0 and u["flags"][0] == 0
+
+
+def test_cli_without_gpu_fails_cleanly(rt):
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(ROOT, "ray-tracing_amd", "rt_cli")
+    r = subprocess.run([exe, "--scene", scene_path("cornell-box"), "--size", "8x8"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2

@@ -23,7 +23,13 @@ ctx = rt.Context(0)
 if args.bvh:
     ml, bins = (int(x) for x in args.bvh.split(","))
     ctx.set_option(106, ml); ctx.set_option(107, bins)
-ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
+if cfg["scene"].startswith("synth:"):
+    from ray_tracing_amd import synth
+    syn = synth.load_config_scene(cfg, ROOT)
+    ctx.scene_upload(syn.vertices, syn.indices, syn.primitives, syn.models)
+    if len(syn.spheres): ctx.spheres_upload(syn.spheres)
+else:
+    ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
 ctx.accum_resize(W, H)
 u = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], max_bounces=cfg["max_bounces"], samples=cfg["samples"],
                     aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]))

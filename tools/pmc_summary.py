@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise a profiles/run_profile.sh output directory: kernel stats + per-launch PMC means + derived figures.
-usage: python tools/pmc_summary.py gpurun_out/prof_<tag> [out_dir]"""
+usage: python tools/pmc_summary.py gpurun_out/prof_<tag> [out_dir [config-key-for-profiles/traffic.json]]"""
 import collections, csv, glob, json, os, shutil, sys
 src = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else None
@@ -32,6 +32,16 @@ if cyc:
         "l2_read_GBps": vals['TCP_TCC_READ_REQ_sum'] * 64 / (avg_ms * 1e-3) / 1e9,
     }
 print(json.dumps(d, indent=1))
+if out and len(sys.argv) > 3:
+    # record the per-launch HBM traffic for bench.py's roofline.traffic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tp = os.path.join(root, "profiles", "traffic.json")
+    t = json.load(open(tp)) if os.path.exists(tp) else {}
+    t[sys.argv[3]] = {"hbm_bytes_per_launch": d["derived"]["hbm_read_bytes_x2"] + d["derived"]["hbm_write_bytes"],
+                      "read_bytes_fetch_size_x2": d["derived"]["hbm_read_bytes_x2"], "write_bytes": d["derived"]["hbm_write_bytes"],
+                      "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE KiB x 2 (gfx950 reads half), WRITE_SIZE KiB x 1",
+                      "profile": out}
+    json.dump(t, open(tp, "w"), indent=1)
 if out:
     os.makedirs(out, exist_ok=True)
     shutil.copy(stats, os.path.join(out, 'kernel_stats.csv'))
