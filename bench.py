@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--cpu-sample", default="3840x2160", help="resolution of the cpu_baseline sample frame")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="after timing, rank 0 re-renders unsharded and compares bit for bit")
     args = ap.parse_args()
 
     import torch
@@ -76,18 +77,26 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # RT_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: all ranks share the visible GPU(s) and the
+    # collectives run on CPU copies.  The real multi-GPU run uses nccl (= RCCL) and one GPU per rank.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective operands live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     rt = graft.load_package()
     sharding = __import__("ray_tracing_amd.sharding", fromlist=["x"])
     cfg = graft.load_config(args.config)
     W, H = cfg["width"], cfg["height"]
 
-    ctx = rt.Context(local_rank)
+    ctx = rt.Context(device_index)
     if cfg["scene"].startswith("synth:"):
         synth = __import__("ray_tracing_amd.synth", fromlist=["x"])
         syn = synth.load_config_scene(cfg, ROOT)
@@ -97,7 +106,13 @@ def main():
         del syn
     else:
         ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
-    stream = torch.cuda.current_stream(dev)
+    # One explicit stream carries everything: torch ops, the render kernels (rt_set_stream) and — through
+    # torch.distributed's stream ordering — the RCCL gather.  (torch's default stream is the null stream,
+    # which rt_set_stream reads as "use the library's own stream"; that would leave the gather unordered
+    # against the kernels.)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     ctx.set_shard(rank, world)
     local = torch.zeros(sharding.local_buffer_floats(W, H, world), dtype=torch.float32, device=dev)
@@ -120,7 +135,11 @@ def main():
     u = fresh_uniform()
     if args.warmup > 0:
         ctx.dispatch_frames(u, args.warmup)
-    img = sharding.gather_framebuffer(local, W, H, rank, world)
+    def gather():
+        src = local if cdev.type == "cuda" else local.cpu()
+        return sharding.gather_framebuffer(src, W, H, rank, world)
+
+    img = gather()
     del img
     barrier()
 
@@ -132,15 +151,15 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ctx.dispatch_frames(u, args.steps)
-    img = sharding.gather_framebuffer(local, W, H, rank, world)
+    img = gather()
     barrier()
     dt = time.perf_counter() - t0
 
     kernel_ms = ctx.last_dispatch_ms() / args.steps        # HIP events on the launch stream, per launch
     stats = ctx.stats()
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    r = torch.tensor([stats.rays, stats.pixel_frames], dtype=torch.int64, device=dev)
-    k = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    r = torch.tensor([stats.rays, stats.pixel_frames], dtype=torch.int64, device=cdev)
+    k = torch.tensor([kernel_ms], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
@@ -184,6 +203,27 @@ def main():
                                "bytes_per_ray": cpu["bytes_per_ray"], "nodes_per_ray": cpu["n_node"],
                                "tris_per_ray": cpu["n_tri"], "hit_fraction": cpu["hit"]}
         print(json.dumps(out), flush=True)
+
+    if args.verify and rank == 0:
+        # the gathered multi-rank image must equal a 1-shard render of the same frames bit for bit
+        ref = rt.Context(device_index)
+        if cfg["scene"].startswith("synth:"):
+            synth = __import__("ray_tracing_amd.synth", fromlist=["x"])
+            syn = synth.load_config_scene(cfg, ROOT)
+            ref.scene_upload(syn.vertices, syn.indices, syn.primitives, syn.models)
+            if len(syn.spheres):
+                ref.spheres_upload(syn.spheres)
+        else:
+            ref.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
+        ref.accum_resize(W, H)
+        ref.dispatch_frames(fresh_uniform(), args.steps)
+        want = ref.accum_download()
+        got = img.cpu().numpy()
+        ok = bool(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+        print(json.dumps({"verify": "gathered image == unsharded render", "n_gpus": world, "identical": ok}), flush=True)
+        ref.close()
+        if not ok:
+            raise SystemExit("verification failed: sharded image differs from the unsharded render")
 
     ctx.close()
     if world > 1:

@@ -381,3 +381,32 @@ def test_headless_cli_capture_matches_oracle(rt, oracle_mod, oracle_scenes, tmp_
         pos_ += 12 + n
     rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
     assert np.array_equal(rows[:, 1:].reshape(h, w, 3), want)
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_contract_and_sharded_image(ranks):
+    """bench.py end to end: prints ONE metric line with roofline fields, and (--verify) the image gathered from
+    `ranks` band shards equals the unsharded render bit for bit.  ranks=2 is a rehearsal on one GPU: both
+    ranks render on the same card and the collectives run over gloo (RT_BENCH_BACKEND), everything else —
+    sharding, stream ordering, counters, the gather and the de-interleave — is the multi-GPU code path."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--verify",
+           "--cpu-sample", "240x135"]
+    if ranks > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", "29533"] + cmd[1:]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=110, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    metric = [l for l in lines if "metric" in l]
+    verify = [l for l in lines if "verify" in l]
+    assert len(metric) == 1 and len(verify) == 1 and verify[0]["identical"] is True
+    m = metric[0]
+    assert m["n_gpus"] == ranks and m["steps"] == 2 and m["unit"] == "Mrays/s" and m["value"] > 0
+    assert m["config"]["rays"] > 3840 * 2160 * 16 * 2
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in m["roofline"]
+    assert m["cpu_baseline"]["kind"] == "port" and m["cpu_baseline"]["value"] > 0
