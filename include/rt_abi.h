@@ -131,6 +131,13 @@ typedef struct RtSphere {
     uint32_t _pad[3];
 } RtSphere;
 
+/* One texture image: RGBA8, rows in FILE order (top row first).  The library
+ * flips it vertically at upload, as src/scene.rs:77 does. */
+typedef struct RtTexture {
+    const uint8_t *rgba8;
+    uint32_t width, height;
+} RtTexture;
+
 /* Accumulation buffer element: array<vec3f> → stride 16 B, xyz @0
  * (shaders/main.wgsl:2, src/app.rs:23). */
 #define RT_ACCUM_STRIDE_BYTES 16u
@@ -191,6 +198,13 @@ int rt_scene_upload(rt_context *ctx,
 /* Build-defined: adds analytic spheres to the scene (BASELINE config C4).
  * Must follow rt_scene_upload; rebuilds the acceleration structure. */
 int rt_spheres_upload(rt_context *ctx, const RtSphere *spheres, uint64_t n_spheres);
+/* ≙ the texture half of Scene::finish, src/scene.rs:69-83 (binding 7,
+ * shaders/main.wgsl:10).  Material texture ids are 1-based indices into this
+ * array (src/scene.rs:170-174).  Sampling = shaders/misc.wgsl:6-8 with the
+ * sampler taken as nearest / clamp-to-edge (the reference's sampler is created
+ * inside the un-vendored `compute` crate: unpinned).
+ * Must follow rt_scene_upload (which clears textures). */
+int rt_textures_upload(rt_context *ctx, const RtTexture *textures, uint32_t n_textures);
 /* ≙ App::upload_models, src/app.rs:46-62: re-upload models (materials) and the
  * per-geometry transforms, then rebuild the acceleration structure
  * (acceleration_structure.update()).  transforms may be NULL (= unchanged). */
@@ -253,7 +267,9 @@ const uint32_t *rt_host_scene_indices(const rt_host_scene *s);
 const RtGeometryPrimitive *rt_host_scene_primitives(const rt_host_scene *s);
 const RtGpuModel *rt_host_scene_models(const rt_host_scene *s);
 const char *rt_host_scene_model_name(const rt_host_scene *s, uint32_t i);
-/* ≙ scene.finish(&gpu), src/main.rs:39 */
+uint32_t rt_host_scene_texture_count(const rt_host_scene *s);
+int rt_host_scene_texture(const rt_host_scene *s, uint32_t i, RtTexture *out);
+/* ≙ scene.finish(&gpu), src/main.rs:39 (scene arrays + textures) */
 int rt_host_scene_finish(const rt_host_scene *s, rt_context *ctx);
 
 /* ≙ the Uniform literal at src/main.rs:73-84 + Camera::default,

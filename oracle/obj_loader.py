@@ -61,12 +61,13 @@ SPHERE_DTYPE = np.dtype(
 
 @dataclass
 class Scene:
-    """≙ struct Scene, src/scene.rs:20-27 (textures omitted: SURVEY §8 N3)."""
+    """≙ struct Scene, src/scene.rs:20-27 ."""
     vertices: np.ndarray
     indices: np.ndarray
     primitives: np.ndarray
     models: np.ndarray
     names: list = field(default_factory=list)
+    textures: list = field(default_factory=list)   # [h, w, 4] uint8 RGBA, file row order (src/scene.rs:23)
 
 
 def _f32(tok: str) -> np.float32:
@@ -108,6 +109,23 @@ def _load_mtl(path: str) -> tuple[list[dict], dict[str, int]]:
             else:
                 cur["unknown"][key] = rest
     return mats, by_name
+
+
+def strip_flags(path: str) -> str:
+    """src/scene.rs:210-223: drop leading `-flag value` pairs of an MTL map statement."""
+    i = 0
+    while path[i:].startswith("-"):
+        for _ in range(2):
+            while not path[i:].startswith(" "):
+                i += 1
+            i += 1
+    return path[i:]
+
+
+def _load_image(path: str) -> np.ndarray:
+    """image::load(...).into_rgba8() (src/scene.rs:163-164), via PIL here."""
+    from PIL import Image
+    return np.array(Image.open(path).convert("RGBA"), np.uint8)
 
 
 def _unknown_f32(mat: dict, key: str) -> np.float32:
@@ -217,6 +235,13 @@ def load(path: str) -> Scene:
     prims = []
     models = []
     names = []
+    textures = []
+
+    def load_texture(rel):                                                # src/scene.rs:157-175
+        if rel is None:
+            return 0
+        textures.append(_load_image(os.path.join(os.path.dirname(path), strip_flags(rel))))
+        return len(textures)
     for name, mat_id, verts, idx in models_out:
         first_vertex = len(all_verts)
         first_index = len(all_idx)
@@ -240,7 +265,9 @@ def load(path: str) -> Scene:
         n2 = np.float32(np.float32(ke[0] * ke[0] + ke[1] * ke[1]) + ke[2] * ke[2])
         norm = np.sqrt(n2, dtype=np.float32)
         em_color = (ke / norm).astype(np.float32) if norm > 0 else np.zeros(3, np.float32)  # :191
-        models.append((0, diffuse, specular, sp, rough, em_color, norm, 0, 0,
+        diffuse_texture = load_texture(mat["diffuse_texture"])            # :177
+        normal_texture = load_texture(mat["normal_texture"])              # :178
+        models.append((0, diffuse, specular, sp, rough, em_color, norm, diffuse_texture, normal_texture,
                        np.float32(0),  # DielectricMaterial::default() → 0.0 (src/types.rs:107)
                        first_vertex, first_index))
         names.append(name)
@@ -257,4 +284,4 @@ def load(path: str) -> Scene:
     for i, t in enumerate(models):
         for name_, val in zip(MODEL_DTYPE.names, t):
             md[name_][i] = val
-    return Scene(v, np.array(all_idx, np.uint32), pr, md, names)
+    return Scene(v, np.array(all_idx, np.uint32), pr, md, names, textures)

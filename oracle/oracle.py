@@ -50,6 +50,7 @@ def lib():
                                           C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_scene_set_front_face_cw.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_scene_triangles.restype = C.c_uint64
         L.oracle_scene_triangles.argtypes = [C.c_void_p]
         L.oracle_scene_nodes.restype = C.c_uint64
@@ -110,6 +111,14 @@ class OracleScene:
             self.models.ctypes.data, len(self.models),
             None if self.spheres is None else self.spheres.ctypes.data,
             0 if self.spheres is None else len(self.spheres), 1 if build_bvh else 0)
+        # textures: list of [h, w, 4] uint8 images in FILE row order; flipped here as src/scene.rs:77 does at upload
+        tex = getattr(scene, "textures", None) or []
+        self._tex = [np.ascontiguousarray(t[::-1], np.uint8) for t in tex]
+        if self._tex:
+            self._tex_ptrs = (C.c_void_p * len(self._tex))(*[t.ctypes.data for t in self._tex])
+            self._tex_w = np.array([t.shape[1] for t in self._tex], np.uint32)
+            self._tex_h = np.array([t.shape[0] for t in self._tex], np.uint32)
+            L.oracle_scene_set_textures(self.handle, self._tex_ptrs, self._tex_w.ctypes.data, self._tex_h.ctypes.data, len(self._tex))
 
     def __del__(self):
         if getattr(self, "handle", None):

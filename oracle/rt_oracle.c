@@ -86,6 +86,11 @@ typedef struct {
     ONode *nodes;
     uint64_t n_nodes;
     int front_face_cw;
+    /* textures[i]: RGBA8 rows as uploaded, i.e. ALREADY flipped vertically
+     * (src/scene.rs:77); texture ids in materials are 1-based (src/scene.rs:170-174) */
+    const uint8_t *const *textures;
+    const uint32_t *tex_w, *tex_h;
+    uint32_t n_textures;
 } OScene;
 
 typedef struct {
@@ -215,15 +220,36 @@ typedef struct {
 
 typedef struct { v3 direction, color; } OScatter;
 
-/* shaders/ray.wgsl:12-32.  Texture paths (normal_texture / diffuse_texture
- * > 0) are SURVEY §8 N3, not exercised by any scene here: ids are ignored. */
-static OScatter scattered_direction_metal(uint32_t *seed, v3 dir, const OIntersection *tr, const OMetal *m) {
+/* shaders/misc.wgsl:6-8: textureSampleLevel(textures[texture], sampler, uv, 0).xyz.
+ * The sampler is created inside the un-vendored `compute` crate (src/main.rs:43), so
+ * its filter/address modes are UNPINNED; the contract takes wgpu's SamplerDescriptor
+ * defaults — nearest filtering, clamp-to-edge — on an Rgba8Unorm texture:
+ * texel = clamp(floor(uv * size), 0, size-1), channel = byte / 255. */
+static v3 sample_rgb(const OScene *sc, uint32_t texture, const float *uv) {
+    if (texture >= sc->n_textures) return V(0.0f, 0.0f, 0.0f);
+    uint32_t w = sc->tex_w[texture], h = sc->tex_h[texture];
+    float fx = floorf(uv[0] * (float)w), fy = floorf(uv[1] * (float)h);
+    fx = (fx > 0.0f) ? fx : 0.0f; fy = (fy > 0.0f) ? fy : 0.0f;          /* NaN -> 0 */
+    fx = (fx < (float)(w - 1)) ? fx : (float)(w - 1);
+    fy = (fy < (float)(h - 1)) ? fy : (float)(h - 1);
+    const uint8_t *px = sc->textures[texture] + 4 * ((size_t)(uint32_t)fy * w + (uint32_t)fx);
+    return V((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+/* shaders/ray.wgsl:12-32 */
+static OScatter scattered_direction_metal(const OScene *sc, uint32_t *seed, v3 dir, const OIntersection *tr, const OMetal *m) {
     float is_specular = (oracle_rand(seed) < m->specular_probability) ? 1.0f : 0.0f;
     float smoothness = 1.0f - m->roughness;
     v3 normal = tr->normal;
+    if (m->normal_texture > 0) {                                          /* ray.wgsl:17-20 */
+        v3 smp = sample_rgb(sc, m->normal_texture - 1, tr->uv);
+        smp = V(smp.x * 2.0f - 1.0f, smp.y * 2.0f - 1.0f, smp.z * 2.0f - 1.0f);
+        normal = tangent_space(normal, smp);
+    }
     v3 diffuse = rand_cosine_hemisphere_vector(seed, normal);
     v3 specular = reflect(dir, normal);
     v3 diffuse_color = V(m->diffuse_color[0], m->diffuse_color[1], m->diffuse_color[2]);
+    if (m->diffuse_texture > 0) diffuse_color = sample_rgb(sc, m->diffuse_texture - 1, tr->uv);   /* ray.wgsl:26 */
     v3 specular_color = V(m->specular_color[0], m->specular_color[1], m->specular_color[2]);
     OScatter r;
     r.direction = mix3(diffuse, specular, smoothness * is_specular);
@@ -447,7 +473,7 @@ static v3 sample_path(const OScene *sc, const OUniform *ctx, uint32_t *seed, flo
         if (tr.material->tag == 0) {
             const OMetal *m = &tr.material->metal;
             v3 emitted = scale(V(m->emission_color[0], m->emission_color[1], m->emission_color[2]), m->emission_strength);
-            OScatter sc2 = scattered_direction_metal(seed, dir, &tr, m);
+            OScatter sc2 = scattered_direction_metal(sc, seed, dir, &tr, m);
             light = add(light, mul(emitted, color));
             color = mul(color, sc2.color);
             pos = add(tr.position, scale(tr.normal, 0.0001f));
@@ -720,6 +746,9 @@ OScene *oracle_scene_create(const OVertex *vertices, uint64_t n_vertices,
     return sc;
 }
 void oracle_scene_set_front_face_cw(OScene *sc, int cw) { sc->front_face_cw = cw; }
+void oracle_scene_set_textures(OScene *sc, const uint8_t *const *textures, const uint32_t *w, const uint32_t *h, uint32_t n) {
+    sc->textures = textures; sc->tex_w = w; sc->tex_h = h; sc->n_textures = n;
+}
 uint64_t oracle_scene_triangles(const OScene *sc) { return sc->n_tris; }
 uint64_t oracle_scene_nodes(const OScene *sc) { return sc->n_nodes; }
 void oracle_scene_destroy(OScene *sc) {

@@ -54,15 +54,20 @@ RT_OPT_FRONT_FACE_CW = 4
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_option",
-    "rt_scene_upload", "rt_spheres_upload", "rt_models_update",
+    "rt_scene_upload", "rt_spheres_upload", "rt_textures_upload", "rt_models_update",
     "rt_set_shard", "rt_accum_local_rows", "rt_accum_resize", "rt_accum_bind",
     "rt_dispatch", "rt_dispatch_frames", "rt_sync",
     "rt_accum_download", "rt_aov_download", "rt_stats", "rt_stats_reset", "rt_last_dispatch_ms",
     "rt_host_scene_load", "rt_host_scene_free", "rt_host_scene_vertex_count", "rt_host_scene_index_count",
     "rt_host_scene_model_count", "rt_host_scene_vertices", "rt_host_scene_indices", "rt_host_scene_primitives",
-    "rt_host_scene_models", "rt_host_scene_model_name", "rt_host_scene_finish",
+    "rt_host_scene_models", "rt_host_scene_model_name", "rt_host_scene_texture_count", "rt_host_scene_texture",
+    "rt_host_scene_finish",
     "rt_host_uniform_default", "rt_host_capture_rgb8", "rt_host_write_png", "rt_host_bvh_info",
 ]
+
+
+class RtTexture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
 class RtStats(C.Structure):
@@ -102,6 +107,10 @@ def lib():
         L.rt_set_option.argtypes = [vp, i32, C.c_int64]
         L.rt_scene_upload.argtypes = [vp, vp, u64, vp, u64, vp, u32, vp, vp, u32]
         L.rt_spheres_upload.argtypes = [vp, vp, u64]
+        L.rt_textures_upload.argtypes = [vp, vp, u32]
+        L.rt_host_scene_texture_count.restype = u32
+        L.rt_host_scene_texture_count.argtypes = [vp]
+        L.rt_host_scene_texture.argtypes = [vp, u32, C.POINTER(RtTexture)]
         L.rt_models_update.argtypes = [vp, vp, u32, vp]
         L.rt_set_shard.argtypes = [vp, u32, u32]
         L.rt_accum_local_rows.restype = u64
@@ -168,6 +177,12 @@ class HostScene:
         self.primitives = view(L.rt_host_scene_primitives(h), PRIMITIVE_DTYPE, nm)
         self.models = view(L.rt_host_scene_models(h), MODEL_DTYPE, nm)
         self.names = [L.rt_host_scene_model_name(h, i).decode() for i in range(nm)]
+        self.textures = []          # [h, w, 4] uint8, file row order
+        for i in range(L.rt_host_scene_texture_count(h)):
+            t = RtTexture()
+            _check(L.rt_host_scene_texture(h, i, C.byref(t)))
+            buf = (C.c_char * (4 * t.width * t.height)).from_address(t.rgba8)
+            self.textures.append(np.frombuffer(buf, np.uint8).copy().reshape(t.height, t.width, 4))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -271,6 +286,15 @@ class Context:
         sp = np.ascontiguousarray(spheres)
         assert sp.dtype.itemsize == 32
         _check(lib().rt_spheres_upload(self.handle, sp.ctypes.data, len(sp)))
+
+    def textures_upload(self, images):
+        """images: list of [h, w, 4] uint8 RGBA arrays in file row order (top row first)."""
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        arr = (RtTexture * max(1, len(imgs)))()
+        for i, im in enumerate(imgs):
+            assert im.ndim == 3 and im.shape[2] == 4
+            arr[i].rgba8, arr[i].width, arr[i].height = im.ctypes.data, im.shape[1], im.shape[0]
+        _check(lib().rt_textures_upload(self.handle, arr, len(imgs)))
 
     def scene_finish(self, host_scene: HostScene):
         _check(lib().rt_host_scene_finish(host_scene.handle, self.handle))

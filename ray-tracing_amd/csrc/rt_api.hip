@@ -64,6 +64,9 @@ struct rt_context {
     std::vector<float> transforms;   // n_primitives x 12, row-major 3x4
     std::vector<RtGpuModel> models;
     std::vector<RtSphere> spheres;   // build-defined primitive (BASELINE config C4)
+    uint32_t n_textures = 0;
+    DevTexture *d_textures = nullptr;
+    uint32_t *d_texels = nullptr;
 
     // device scene
     DevNode *d_nodes = nullptr;
@@ -285,6 +288,8 @@ int build_and_upload(rt_context *ctx) {
         for (int k = 0; k < 3; k++) d.emitted[k] = m.metal.emission_color[k] * m.metal.emission_strength;  // main.wgsl:56
         d.refractive_index = m.refractive_index;
         d.tag = m.tag;
+        d.diffuse_texture = m.metal.diffuse_texture;
+        d.normal_texture = m.metal.normal_texture;
     }
 
     RT_HIP(hipSetDevice(ctx->device));
@@ -330,6 +335,7 @@ int launch(rt_context *ctx, const RtUniform &u) {
     RenderParams P;
     memset(&P, 0, sizeof P);
     P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
+    P.textures = ctx->d_textures; P.texels = ctx->d_texels; P.n_textures = ctx->n_textures;
     P.accum = ctx->d_accum;
     P.aov = ctx->opt_aov ? ctx->d_aov : nullptr;
     P.counters = ctx->d_counters;
@@ -365,7 +371,7 @@ int launch(rt_context *ctx, const RtUniform &u) {
         RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
         if (ctx->persistent_blocks == 0) ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries);
     }
-    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->spheres.empty(), ctx->persistent_blocks, ctx->stream));
+    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->spheres.empty() || ctx->n_textures > 0, ctx->persistent_blocks, ctx->stream));
     ctx->dispatches++;
     return RT_OK;
 }
@@ -422,6 +428,7 @@ int rt_destroy(rt_context *ctx) {
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
     if (ctx->accum_owned) dev_free(ctx->d_accum);
     dev_free(ctx->d_aov); dev_free(ctx->d_counters); dev_free(ctx->d_queue);
+    dev_free(ctx->d_textures); dev_free(ctx->d_texels);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -466,6 +473,7 @@ int rt_scene_upload(rt_context *ctx, const RtVertex *vertices, uint64_t n_vertic
     if (transforms) ctx->transforms.assign(transforms, transforms + 12ull * n_primitives);
     else ctx->transforms.clear();
     ctx->spheres.clear();
+    ctx->n_textures = 0;
     ctx->have_scene = false;
     return build_and_upload(ctx);
 }
@@ -475,6 +483,39 @@ int rt_spheres_upload(rt_context *ctx, const RtSphere *spheres, uint64_t n_spher
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_spheres_upload before rt_scene_upload");
     ctx->spheres.assign(spheres, spheres + n_spheres);
     return build_and_upload(ctx);
+}
+
+int rt_textures_upload(rt_context *ctx, const RtTexture *textures, uint32_t n_textures) {
+    if (!ctx || (n_textures && !textures)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_textures_upload before rt_scene_upload");
+    std::vector<DevTexture> table(n_textures ? n_textures : 1);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_textures; i++) {
+        if (!textures[i].rgba8 || textures[i].width == 0 || textures[i].height == 0)
+            return fail(RT_ERR_INVALID_ARGUMENT, "texture %u is empty", i);
+        if (total + (uint64_t)textures[i].width * textures[i].height > 0xFFFFFFFFull)
+            return fail(RT_ERR_INVALID_ARGUMENT, "more than 2^32 texels in total");
+        table[i].offset = (uint32_t)total;
+        table[i].width = textures[i].width;
+        table[i].height = textures[i].height;
+        table[i].pad = 0;
+        total += (uint64_t)textures[i].width * textures[i].height;
+    }
+    std::vector<uint32_t> texels(total ? total : 1);
+    for (uint32_t i = 0; i < n_textures; i++) {
+        const uint32_t w = textures[i].width, h = textures[i].height;
+        for (uint32_t y = 0; y < h; y++)   // imageops::flip_vertical, src/scene.rs:77
+            memcpy(&texels[table[i].offset + (size_t)y * w], textures[i].rgba8 + 4 * (size_t)(h - 1 - y) * w, 4 * (size_t)w);
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_textures); dev_free(ctx->d_texels);
+    RT_HIP(hipMalloc((void **)&ctx->d_textures, table.size() * sizeof(DevTexture)));
+    RT_HIP(hipMalloc((void **)&ctx->d_texels, texels.size() * sizeof(uint32_t)));
+    RT_HIP(hipMemcpy(ctx->d_textures, table.data(), table.size() * sizeof(DevTexture), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(ctx->d_texels, texels.data(), texels.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->n_textures = n_textures;
+    return RT_OK;
 }
 
 int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models, const float *transforms) {
@@ -627,9 +668,17 @@ int rt_last_dispatch_ms(rt_context *ctx, float *ms) {
 int rt_host_scene_finish(const rt_host_scene *s, rt_context *ctx) {
     if (!s || !ctx) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     const rt_host::Scene &sc = s->scene;
-    return rt_scene_upload(ctx, sc.vertices.data(), sc.vertices.size(), sc.indices.data(), sc.indices.size(),
-                           sc.primitives.data(), (uint32_t)sc.primitives.size(), nullptr, sc.models.data(),
-                           (uint32_t)sc.models.size());
+    int r = rt_scene_upload(ctx, sc.vertices.data(), sc.vertices.size(), sc.indices.data(), sc.indices.size(),
+                            sc.primitives.data(), (uint32_t)sc.primitives.size(), nullptr, sc.models.data(),
+                            (uint32_t)sc.models.size());
+    if (r || sc.textures.empty()) return r;
+    std::vector<RtTexture> tex(sc.textures.size());
+    for (size_t i = 0; i < tex.size(); i++) {
+        tex[i].rgba8 = sc.textures[i].rgba.data();
+        tex[i].width = sc.textures[i].width;
+        tex[i].height = sc.textures[i].height;
+    }
+    return rt_textures_upload(ctx, tex.data(), (uint32_t)tex.size());
 }
 
 }  // extern "C"

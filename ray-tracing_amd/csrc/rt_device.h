@@ -56,9 +56,15 @@ struct alignas(16) DevMaterial {
     float diffuse[3];  float specular_probability;
     float specular[3]; float roughness;
     float emitted[3];  float refractive_index;    // emitted = emission_color * emission_strength (main.wgsl:56)
-    uint32_t tag, pad[3];
+    uint32_t tag, diffuse_texture, normal_texture, pad;   // texture ids 1-based, 0 = none (src/scene.rs:170-174)
 };
 static_assert(sizeof(DevMaterial) == 64, "DevMaterial");
+
+// one texture: w x h RGBA8 texels starting at `offset` (in texels) of the packed
+// texel array, rows already flipped vertically (src/scene.rs:77)
+struct DevTexture {
+    uint32_t offset, width, height, pad;
+};
 
 struct DevCounters {
     unsigned long long rays, pixel_frames, node_visits, triangle_tests;
@@ -77,6 +83,9 @@ struct RenderParams {
     const DevTri *tris;
     const DevShade *shade;
     const DevMaterial *materials;
+    const DevTexture *textures;   // EXT builds only
+    const uint32_t *texels;
+    uint32_t n_textures, pad_tex;
     float *accum;            // local rows x W x 4 f32
     uint32_t *aov;           // local rows x W x 2 u32, or null
     DevCounters *counters;

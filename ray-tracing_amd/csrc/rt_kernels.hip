@@ -217,6 +217,19 @@ __device__ __forceinline__ rt_v3 rand_cosine_hemisphere_vector(uint32_t &seed, r
     return tangent_space(normal, s);
 }
 
+// shaders/misc.wgsl:6-8 with a nearest / clamp-to-edge sampler on an Rgba8Unorm texture
+// (sampler unpinned, see rt_abi.h rt_textures_upload): texel = clamp(floor(uv*size), 0, size-1)
+__device__ __forceinline__ rt_v3 sample_rgb(const RenderParams &P, uint32_t texture, float u, float v) {
+    if (texture >= P.n_textures) return v3(0.0f, 0.0f, 0.0f);
+    const DevTexture t = P.textures[texture];
+    float fx = floorf(u * (float)t.width), fy = floorf(v * (float)t.height);
+    fx = (fx > 0.0f) ? fx : 0.0f; fy = (fy > 0.0f) ? fy : 0.0f;          // NaN -> 0
+    fx = (fx < (float)(t.width - 1)) ? fx : (float)(t.width - 1);
+    fy = (fy < (float)(t.height - 1)) ? fy : (float)(t.height - 1);
+    const uint32_t px = P.texels[t.offset + (uint32_t)fy * t.width + (uint32_t)fx];
+    return v3((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);
+}
+
 // shaders/main.wgsl:104-108, pow(x, 5.0) as ((x*x)*(x*x))*x
 __device__ __forceinline__ float schlick_approximation(float cos_theta, float ri) {
     float r = (1.0f - ri) / (1.0f + ri);
@@ -335,13 +348,28 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
         float4 m0 = ld4(&mp->diffuse[0]), m1 = ld4(&mp->specular[0]), m2 = ld4(&mp->emitted[0]);
         const uint32_t tag = mp->tag;
         if (tag == 0u) {                                            // main.wgsl:53-61
-            // get_scattered_direction_metal, ray.wgsl:12-32 (texture ids ignored: SURVEY §8 N3)
+            // get_scattered_direction_metal, ray.wgsl:12-32
             float is_specular = (rt_rand(S.seed) < m0.w) ? 1.0f : 0.0f;
             float smoothness = 1.0f - m1.w;
-            rt_v3 diffuse = rand_cosine_hemisphere_vector(S.seed, normal);
-            rt_v3 specular = rt_reflect(S.dir, normal);
+            rt_v3 scatter_normal = normal;
+            rt_v3 diffuse_color = v3(m0.x, m0.y, m0.z);
+            if (SPH && (mp->normal_texture | mp->diffuse_texture) != 0u) {
+                // trace.uv, main.wgsl:96 (spheres: uv = 0)
+                float tu = 0.0f, tv = 0.0f;
+                if (!(sh->geometry & 0x80000000u)) {
+                    tu = s1.z * b0 + s3.z * b1 + s5.z * b2;
+                    tv = s1.w * b0 + s3.w * b1 + s5.w * b2;
+                }
+                if (mp->normal_texture > 0u) {                              // ray.wgsl:17-20
+                    rt_v3 smp = sample_rgb(P, mp->normal_texture - 1u, tu, tv);
+                    scatter_normal = tangent_space(normal, v3(smp.x * 2.0f - 1.0f, smp.y * 2.0f - 1.0f, smp.z * 2.0f - 1.0f));
+                }
+                if (mp->diffuse_texture > 0u) diffuse_color = sample_rgb(P, mp->diffuse_texture - 1u, tu, tv);   // ray.wgsl:26
+            }
+            rt_v3 diffuse = rand_cosine_hemisphere_vector(S.seed, scatter_normal);
+            rt_v3 specular = rt_reflect(S.dir, scatter_normal);
             rt_v3 sdir = rt_mix(diffuse, specular, smoothness * is_specular);
-            rt_v3 scol = rt_mix(v3(m0.x, m0.y, m0.z), v3(m1.x, m1.y, m1.z), is_specular);
+            rt_v3 scol = rt_mix(diffuse_color, v3(m1.x, m1.y, m1.z), is_specular);
             S.light = S.light + v3(m2.x, m2.y, m2.z) * S.color;
             S.color = S.color * scol;
             S.pos = position + normal * 0.0001f;

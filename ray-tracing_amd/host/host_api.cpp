@@ -35,6 +35,16 @@ const char *rt_host_scene_model_name(const rt_host_scene *s, uint32_t i) {
     return (s && i < s->scene.names.size()) ? s->scene.names[i].c_str() : nullptr;
 }
 
+uint32_t rt_host_scene_texture_count(const rt_host_scene *s) { return s ? (uint32_t)s->scene.textures.size() : 0; }
+int rt_host_scene_texture(const rt_host_scene *s, uint32_t i, RtTexture *out) {
+    if (!s || !out || i >= s->scene.textures.size()) { rt_set_last_error("texture index out of range"); return RT_ERR_INVALID_ARGUMENT; }
+    const rt_host::Image &im = s->scene.textures[i];
+    out->rgba8 = im.rgba.data();
+    out->width = im.width;
+    out->height = im.height;
+    return RT_OK;
+}
+
 void rt_host_uniform_default(RtUniform *u) { if (u) rt_host::uniform_default(*u); }
 
 void rt_host_capture_rgb8(const float *src, uint64_t n_pixels, uint8_t *dst) { rt_host::capture_rgb8(src, n_pixels, dst); }

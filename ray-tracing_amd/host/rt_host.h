@@ -10,8 +10,15 @@
 
 namespace rt_host {
 
-// ≙ struct Scene, /root/reference/src/scene.rs:20-27 (textures: SURVEY §8 N3)
+// one decoded texture: RGBA8, rows in file order (top row first)
+struct Image {
+    uint32_t width = 0, height = 0;
+    std::vector<uint8_t> rgba;
+};
+
+// ≙ struct Scene, /root/reference/src/scene.rs:20-27
 struct Scene {
+    std::vector<Image> textures;
     std::vector<RtVertex> vertices;
     std::vector<uint32_t> indices;
     std::vector<RtGeometryPrimitive> primitives;
@@ -21,6 +28,10 @@ struct Scene {
 
 // ≙ Scene::load, src/scene.rs:95-207
 bool load_obj(const std::string &path, Scene &scene, std::string &err);
+// ≙ image::load(...).into_rgba8(), src/scene.rs:157-170 (PNG and binary PPM)
+bool load_image_rgba8(const std::string &path, Image &img, std::string &err);
+// ≙ strip_flags, src/scene.rs:210-223
+std::string strip_flags(const std::string &path);
 
 // ---------------------------------------------------------------- BVH build
 // The reference hands BVH construction to the Vulkan driver

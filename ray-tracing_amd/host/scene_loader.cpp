@@ -28,7 +28,7 @@ struct MtlMaterial {
     std::string name;
     float diffuse[3] = {0, 0, 0};
     float specular[3] = {0, 0, 0};
-    bool has_diffuse_texture = false, has_normal_texture = false;
+    std::string diffuse_texture, normal_texture;   // tobj Material::diffuse_texture / normal_texture (empty = None)
     std::unordered_map<std::string, std::string> unknown;  // tobj Material::unknown_param
 };
 
@@ -85,9 +85,9 @@ bool load_mtl(const std::string &path, std::vector<MtlMaterial> &mats,
             const char *p = rest.c_str();
             for (int k = 0; k < 3; k++) if (!parse_f32(p, dst[k])) { err = "bad " + key + " in " + path; return false; }
         } else if (key == "map_Kd") {
-            cur->has_diffuse_texture = true;
+            cur->diffuse_texture = rest;
         } else if (key == "map_Bump" || key == "map_bump" || key == "bump") {
-            cur->has_normal_texture = true;
+            cur->normal_texture = rest;
         } else if (key == "Ka" || key == "Ns" || key == "Ni" || key == "d" || key == "illum" ||
                    key == "map_Ka" || key == "map_Ks" || key == "map_Ns" || key == "map_d") {
             // parsed by tobj into fields the reference never reads
@@ -202,7 +202,18 @@ bool load_obj(const std::string &path, Scene &scene, std::string &err) {
         float norm = sqrtf(n2);
         if (norm > 0.0f) for (int k = 0; k < 3; k++) model.material.metal.emission_color[k] = ke[k] / norm;  // :191
         model.material.metal.emission_strength = norm;                   // :192
-        // textures: SURVEY §8 N3 (none of the scenes has a map_* line); ids stay 0
+        // load_texture, src/scene.rs:157-178: 1-based id of the pushed image, 0 = none; not de-duplicated
+        auto load_texture = [&](const std::string &rel, uint32_t &id) -> bool {
+            id = 0;
+            if (rel.empty()) return true;
+            Image img;
+            if (!load_image_rgba8(dir + "/" + strip_flags(rel), img, err)) return false;
+            scene.textures.push_back(std::move(img));
+            id = (uint32_t)scene.textures.size();
+            return true;
+        };
+        if (!load_texture(m.diffuse_texture, model.material.metal.diffuse_texture)) return false;   // :177
+        if (!load_texture(m.normal_texture, model.material.metal.normal_texture)) return false;     // :178
         model.material.refractive_index = 0.0f;                          // DielectricMaterial::default()
         model.vertex_start = first_vertex;                               // :197
         model.index_start = first_index;                                 // :198
