@@ -162,7 +162,9 @@ typedef struct RtStats {
     uint64_t dispatches;
     uint64_t bvh_nodes;       /* static: nodes in the device BVH */
     uint64_t bvh_bytes;       /* static: bytes of nodes + triangle records on device */
-    double   bvh_build_seconds;
+    double   bvh_build_seconds; /* last build or refit */
+    uint64_t bvh_refits;      /* rt_models_update calls served by a refit */
+    uint64_t bvh_rebuilds;    /* full builds (scene/sphere uploads, refit disabled) */
 } RtStats;
 
 /* rt_set_option keys */
@@ -170,6 +172,8 @@ typedef struct RtStats {
 #define RT_OPT_AOV             2   /* 0/1: write primary hit ids on every dispatch */
 #define RT_OPT_KERNEL          3   /* kernel variant; 0 = default */
 #define RT_OPT_FRONT_FACE_CW   4   /* 0 (default): CCW = front; 1: CW = front */
+#define RT_OPT_REFIT           5   /* 1 (default): rt_models_update refits the BVH (≙ acceleration_structure.update(),
+                                      src/app.rs:61); 0: full rebuild */
 
 typedef struct rt_context rt_context;
 
@@ -207,7 +211,9 @@ int rt_spheres_upload(rt_context *ctx, const RtSphere *spheres, uint64_t n_spher
 int rt_textures_upload(rt_context *ctx, const RtTexture *textures, uint32_t n_textures);
 /* ≙ App::upload_models, src/app.rs:46-62: re-upload models (materials) and the
  * per-geometry transforms, then rebuild the acceleration structure
- * (acceleration_structure.update()).  transforms may be NULL (= unchanged). */
+ * (acceleration_structure.update()): the tree topology is kept and its boxes
+ * are refitted to the moved triangles (RT_OPT_REFIT=0 forces a full rebuild).
+ * transforms may be NULL (= unchanged). */
 int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models,
                      const float *transforms);
 
@@ -275,6 +281,25 @@ int rt_host_scene_finish(const rt_host_scene *s, rt_context *ctx);
 /* ≙ the Uniform literal at src/main.rs:73-84 + Camera::default,
  * src/camera.rs:112-123 */
 void rt_host_uniform_default(RtUniform *u);
+
+/* ≙ struct App's frame state, src/app.rs:20-38 (pipelines and buffers live in
+ * rt_context): what App::render needs between frames. */
+typedef struct RtAppState {
+    RtUniform uniform;           /* src/app.rs:25 */
+    uint32_t inner_size[2];      /* gcx.window.inner_size(), src/app.rs:83 */
+    uint32_t last_window[2];     /* src/app.rs:35 */
+    double   last_invalidation;  /* seconds; src/app.rs:34 (an Instant there) */
+    uint8_t  accumulate;         /* src/app.rs:36 */
+    uint8_t  screen_fraction;    /* src/app.rs:37 */
+    uint8_t  _pad[6];
+} RtAppState;
+void rt_host_app_init(RtAppState *app, uint32_t inner_width, uint32_t inner_height, double now);
+void rt_host_app_invalidate(RtAppState *app, double now);
+int rt_host_app_set_params(RtAppState *app, const RtUniform *edited, double now);
+int rt_host_app_begin_frame(RtAppState *app, double now);
+/* ≙ App::render, src/app.rs:74-102, against a context: begin_frame, re-create the
+ * zeroed accumulation buffer when the window changed, dispatch.  Asynchronous. */
+int rt_app_render(rt_context *ctx, RtAppState *app, double now);
 
 /* Capture ≙ src/ui.rs:82-93: (x*255) as u8 per channel (truncating,
  * saturating), RGB8.  src = n_pixels 16-B elements; dst = n_pixels*3 bytes. */

@@ -51,6 +51,7 @@ RT_OPT_COUNT_TRAVERSAL = 1
 RT_OPT_AOV = 2
 RT_OPT_KERNEL = 3
 RT_OPT_FRONT_FACE_CW = 4
+RT_OPT_REFIT = 5
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_option",
@@ -63,6 +64,7 @@ EXPORTS = [
     "rt_host_scene_models", "rt_host_scene_model_name", "rt_host_scene_texture_count", "rt_host_scene_texture",
     "rt_host_scene_finish",
     "rt_host_uniform_default", "rt_host_capture_rgb8", "rt_host_write_png", "rt_host_bvh_info",
+    "rt_host_app_init", "rt_host_app_invalidate", "rt_host_app_set_params", "rt_host_app_begin_frame", "rt_app_render",
 ]
 
 
@@ -70,11 +72,44 @@ class RtTexture(C.Structure):
     _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
+APP_DTYPE = np.dtype(
+    {"names": ["uniform", "inner_size", "last_window", "last_invalidation", "accumulate", "screen_fraction"],
+     "formats": [UNIFORM_DTYPE, (np.uint32, 2), (np.uint32, 2), np.float64, np.uint8, np.uint8],
+     "offsets": [0, 80, 88, 96, 104, 105], "itemsize": 112})
+
+
+class App:
+    """≙ struct App + App::render (src/app.rs:20-103), headless; time is passed in."""
+
+    def __init__(self, inner_width, inner_height, now=0.0):
+        self.state = np.zeros(1, APP_DTYPE)
+        lib().rt_host_app_init(self.state.ctypes.data, inner_width, inner_height, C.c_double(now))
+
+    @property
+    def uniform(self):
+        return self.state["uniform"]
+
+    def invalidate(self, now):
+        lib().rt_host_app_invalidate(self.state.ctypes.data, C.c_double(now))
+
+    def set_params(self, edited_uniform, now):
+        u = np.ascontiguousarray(edited_uniform)
+        return bool(lib().rt_host_app_set_params(self.state.ctypes.data, u.ctypes.data, C.c_double(now)))
+
+    def begin_frame(self, now):
+        return bool(lib().rt_host_app_begin_frame(self.state.ctypes.data, C.c_double(now)))
+
+    def render(self, ctx, now):
+        _check(lib().rt_app_render(ctx.handle, self.state.ctypes.data, C.c_double(now)))
+        ctx.width, ctx.height = int(self.uniform["window"][0][0]), int(self.uniform["window"][0][1])
+
+
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("pixel_frames", C.c_uint64), ("node_visits", C.c_uint64),
                 ("triangle_tests", C.c_uint64), ("wave_node_iters", C.c_uint64), ("wave_leaf_iters", C.c_uint64),
                 ("wave_steps", C.c_uint64), ("dispatches", C.c_uint64), ("bvh_nodes", C.c_uint64),
-                ("bvh_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double)]
+                ("bvh_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double), ("bvh_refits", C.c_uint64),
+                ("bvh_rebuilds", C.c_uint64)]
 
 
 class RtBvhInfo(C.Structure):
@@ -145,6 +180,13 @@ def lib():
         L.rt_host_capture_rgb8.restype = None
         L.rt_host_write_png.argtypes = [C.c_char_p, vp, u32, u32]
         L.rt_host_bvh_info.argtypes = [vp, u64, vp, u64, vp, u32, vp, C.POINTER(RtBvhInfo)]
+        L.rt_host_app_init.argtypes = [vp, u32, u32, C.c_double]
+        L.rt_host_app_init.restype = None
+        L.rt_host_app_invalidate.argtypes = [vp, C.c_double]
+        L.rt_host_app_invalidate.restype = None
+        L.rt_host_app_set_params.argtypes = [vp, vp, C.c_double]
+        L.rt_host_app_begin_frame.argtypes = [vp, C.c_double]
+        L.rt_app_render.argtypes = [vp, vp, C.c_double]
         _lib = L
     return _lib
 

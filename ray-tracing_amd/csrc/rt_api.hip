@@ -76,6 +76,9 @@ struct rt_context {
     uint64_t n_nodes = 0, n_tris = 0;
     uint32_t stack_entries = 1;
     bool have_scene = false;
+    rt_host::Bvh2 bvh;               // kept for refits (rt_models_update)
+    uint64_t bvh_prims = 0;
+    uint64_t refits = 0, rebuilds = 0;
     double build_seconds = 0.0;
 
     // accumulation
@@ -93,7 +96,7 @@ struct rt_context {
     int persistent_blocks = 0;
     uint64_t dispatches = 0;
 
-    bool opt_count = false, opt_aov = false, opt_cw = false;
+    bool opt_count = false, opt_aov = false, opt_cw = false, opt_refit = true;
     int opt_kernel = 2;
     int32_t tune[8] = {4, 4, 2, 4, 64, 0, 0, 0};
     bool timed = false;
@@ -229,7 +232,7 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
     out.stack_entries = bvh.max_depth + 2;
 }
 
-int build_and_upload(rt_context *ctx) {
+int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     std::string err;
     std::vector<float> corners;
     std::vector<uint32_t> ids;
@@ -267,11 +270,19 @@ int build_and_upload(rt_context *ctx) {
         const float r = sp.radius * 1.0001f + 1e-6f;   // the quadratic's roots are not exact
         for (int k = 0; k < 3; k++) { boxes[n_tris + i].lo[k] = sp.center[k] - r; boxes[n_tris + i].hi[k] = sp.center[k] + r; }
     }
-    rt_host::Bvh2 bvh;
-    rt_host::BvhBuildOptions opt;
-    if (ctx->tune[6] > 0) opt.max_leaf = (uint32_t)ctx->tune[6];
-    if (ctx->tune[7] > 0) opt.bins = (uint32_t)ctx->tune[7];
-    rt_host::build_bvh2(boxes.data(), n_prims, opt, bvh);
+    rt_host::Bvh2 &bvh = ctx->bvh;
+    if (allow_refit && ctx->opt_refit && ctx->bvh_prims == n_prims && n_prims > 0) {
+        // ≙ acceleration_structure.update(), src/app.rs:61: same primitives, moved
+        rt_host::refit_bvh2(boxes.data(), bvh);
+        ctx->refits++;
+    } else {
+        rt_host::BvhBuildOptions opt;
+        if (ctx->tune[6] > 0) opt.max_leaf = (uint32_t)ctx->tune[6];
+        if (ctx->tune[7] > 0) opt.bins = (uint32_t)ctx->tune[7];
+        rt_host::build_bvh2(boxes.data(), n_prims, opt, bvh);
+        ctx->bvh_prims = n_prims;
+        ctx->rebuilds++;
+    }
     Repacked rp;
     repack(bvh, corners, ids, *ctx, rp);
     ctx->build_seconds = bvh.build_seconds;
@@ -451,6 +462,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
         case RT_OPT_AOV: ctx->opt_aov = value != 0; return RT_OK;
         case RT_OPT_KERNEL: ctx->opt_kernel = (int)value; return RT_OK;
         case RT_OPT_FRONT_FACE_CW: ctx->opt_cw = value != 0; return RT_OK;
+        case RT_OPT_REFIT: ctx->opt_refit = value != 0; return RT_OK;
         default:
             if (key >= 100 && key < 108) { ctx->tune[key - 100] = (int32_t)value; return RT_OK; }
             return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);
@@ -523,7 +535,7 @@ int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_model
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_models_update before rt_scene_upload");
     ctx->models.assign(models, models + n_models);
     if (transforms) ctx->transforms.assign(transforms, transforms + 12ull * ctx->primitives.size());
-    return build_and_upload(ctx);
+    return build_and_upload(ctx, /*allow_refit=*/true);
 }
 
 int rt_set_shard(rt_context *ctx, uint32_t shard_index, uint32_t shard_count) {
@@ -645,6 +657,8 @@ int rt_stats(rt_context *ctx, RtStats *out) {
     out->bvh_nodes = ctx->n_nodes;
     out->bvh_bytes = ctx->n_nodes * sizeof(DevNode) + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));
     out->bvh_build_seconds = ctx->build_seconds;
+    out->bvh_refits = ctx->refits;
+    out->bvh_rebuilds = ctx->rebuilds;
     return RT_OK;
 }
 
@@ -663,6 +677,17 @@ int rt_last_dispatch_ms(rt_context *ctx, float *ms) {
     RT_HIP(hipEventSynchronize(ctx->ev1));
     RT_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return RT_OK;
+}
+
+int rt_app_render(rt_context *ctx, RtAppState *app, double now) {
+    if (!ctx || !app) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    const int resized = rt_host_app_begin_frame(app, now);
+    if (app->uniform.window[0] == 0 || app->uniform.window[1] == 0) return RT_OK;   // nothing to dispatch
+    if (resized || !ctx->d_accum || ctx->width != app->uniform.window[0] || ctx->height != app->uniform.window[1]) {
+        int r = rt_accum_resize(ctx, app->uniform.window[0], app->uniform.window[1]);   // src/app.rs:87-93
+        if (r) return r;
+    }
+    return rt_dispatch(ctx, &app->uniform);                                            // src/app.rs:97-101
 }
 
 int rt_host_scene_finish(const rt_host_scene *s, rt_context *ctx) {

@@ -247,6 +247,25 @@ void build_bvh2(const Aabb *boxes, uint64_t n, const BvhBuildOptions &opt_in, Bv
     out.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
+void refit_bvh2(const Aabb *boxes, Bvh2 &bvh) {
+    auto t0 = std::chrono::steady_clock::now();
+    for (size_t i = bvh.nodes.size(); i-- > 0;) {
+        Bvh2Node &n = bvh.nodes[i];
+        Box3 b;
+        if (n.count) {
+            for (uint32_t k = 0; k < n.count; k++) b.grow(boxes[bvh.order[n.left + k]].lo, boxes[bvh.order[n.left + k]].hi);
+        } else if (bvh.nodes.size() > 1) {
+            b.grow(bvh.nodes[n.left].box.lo, bvh.nodes[n.left].box.hi);
+            b.grow(bvh.nodes[n.left + 1].box.lo, bvh.nodes[n.left + 1].box.hi);
+        } else {
+            continue;   // empty tree
+        }
+        memcpy(n.box.lo, b.lo, 12);
+        memcpy(n.box.hi, b.hi, 12);
+    }
+    bvh.build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 bool gather_triangles(const RtVertex *vertices, uint64_t n_vertices, const uint32_t *indices, uint64_t n_indices,
                       const RtGeometryPrimitive *prims, uint32_t n_prims, const float *transforms,
                       std::vector<float> &corners, std::vector<uint32_t> &ids, std::string &err) {

@@ -67,6 +67,9 @@ struct BvhBuildOptions {
 
 // boxes[i] bounds primitive i.  n may be 0 (empty tree: one empty leaf).
 void build_bvh2(const Aabb *boxes, uint64_t n, const BvhBuildOptions &opt, Bvh2 &out);
+// ≙ acceleration_structure.update(), src/app.rs:61: keep the tree's topology, recompute every box
+// bottom-up from the primitives' new bounds (children always follow their parent in `nodes`).
+void refit_bvh2(const Aabb *boxes, Bvh2 &bvh);
 
 // Triangle corner positions for the BLAS: index triples of each
 // GeometryPrimitive with that geometry's 3x4 transform applied

@@ -410,3 +410,58 @@ def test_bench_contract_and_sharded_image(ranks):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in m["roofline"]
     assert m["cpu_baseline"]["kind"] == "port" and m["cpu_baseline"]["value"] > 0
+
+
+def test_models_update_refits_bvh(rt, oracle_mod, scenes):
+    """rt_models_update ≙ App::upload_models (src/app.rs:46-62): new transforms refit the existing tree
+    (acceleration_structure.update()); the image still equals the oracle's for the moved geometry."""
+    cfg = config("C2")
+    w, h = 80, 45
+    s = scenes("teapot")
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(s.primitives), 1))
+    moved = ident.copy()
+    moved[0] = [0.7, 0.2, 0, 0.5, -0.2, 0.9, 0, 0.3, 0, 0, 1.2, -0.4]
+    moved[2] = [1, 0, 0, 0.2, 0, 1, 0, -0.1, 0, 0, 1, 0.3]
+    want, want_hits, _ = oracle_mod.OracleScene(s, transforms=moved).render(uniforms_for(oracle_mod, cfg, w, h, samples=3), mode=1, want_hits=True)
+    with rt.Context(0) as ctx:
+        ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models, transforms=ident)
+        ctx.set_option(rt.RT_OPT_AOV, 1)
+        for refit in (1, 0):
+            ctx.set_option(rt.RT_OPT_REFIT, refit)
+            ctx.models_update(s.models, transforms=ident)
+            ctx.models_update(s.models, transforms=moved)
+            ctx.accum_resize(w, h)
+            ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=3))
+            assert np.array_equal(ctx.aov_download(), want_hits)
+            assert_images_identical(ctx.accum_download(), want, f"refit={refit}")
+        st = ctx.stats()
+        assert st.bvh_refits == 2 and st.bvh_rebuilds == 3
+
+
+def test_app_render_matches_oracle_frames(rt, oracle_mod, oracle_scenes):
+    """rt_app_render ≙ App::render (src/app.rs:74-102) driven headless: after the window has settled the
+    accumulation buffer equals the oracle's running mean over the same (frame, accumulation_frame) pairs."""
+    cfg = config("C1")
+    app = rt.App(64, 48, now=0.0)
+    app.state["screen_fraction"] = 1
+    edited = app.uniform.copy()
+    edited["position"][0] = cfg["position"]
+    edited["yaw"], edited["pitch"] = np.float32(cfg["yaw"]), np.float32(cfg["pitch"])
+    edited["samples"], edited["max_bounces"] = 2, 3
+    app.set_params(edited, 0.0)
+    with rt.Context(0) as ctx:
+        ctx.scene_finish(rt.HostScene(scene_path("cornell-box")))
+        seen = []
+        for t in [0.0, 0.5, 1.0, 1.1, 1.2, 1.3]:      # the first frames render at 1/4, 1/2 size, then 64x48 settles at t=1.0
+            app.render(ctx, t)
+            u = app.uniform[0]
+            seen.append((tuple(int(x) for x in u["window"]), int(u["frame"]), int(u["accumulation_frame"])))
+        got = ctx.accum_download()
+    assert seen[-4:] == [((64, 48), 3, 0), ((64, 48), 4, 1), ((64, 48), 5, 2), ((64, 48), 6, 3)]
+    ou = oracle_mod.make_uniform(64, 48, cfg["position"], cfg["yaw"], cfg["pitch"], max_bounces=3, samples=2,
+                                 aspect=np.float32(64) / np.float32(48))
+    acc = np.zeros((48, 64, 4), np.float32)
+    for frame, af in [(3, 0), (4, 1), (5, 2), (6, 3)]:
+        ou["frame"], ou["accumulation_frame"] = frame, af
+        oracle_scenes("cornell-box").render(ou, acc, mode=1)
+    assert_images_identical(got, acc, "app frames")

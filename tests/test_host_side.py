@@ -190,3 +190,60 @@ def test_cli_without_gpu_fails_cleanly(rt):
     assert r.returncode == 1 and "no HIP device" in r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2
+
+
+def test_app_state_layout(rt):
+    import subprocess
+    src = '#include "include/rt_abi.h"\nstatic_assert(sizeof(RtAppState) == 112, "");\nstatic_assert(offsetof(RtAppState, inner_size) == 80, "");\nstatic_assert(offsetof(RtAppState, last_invalidation) == 96, "");\nstatic_assert(offsetof(RtAppState, accumulate) == 104, "");\nint main(){}\n'
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-I", ROOT, "-"], input=src, text=True, check=True, cwd=ROOT)
+    assert rt.APP_DTYPE.itemsize == 112
+
+
+def test_app_frame_sequence(rt):
+    """App::render bookkeeping (src/app.rs:74-96) from a cold start, the reference's invalidation quirk and the
+    progressive screen fraction."""
+    app = rt.App(1600, 900, now=0.0)
+    seq = []
+    # first second: dynamic fraction 4 -> 1 dominates screen_fraction 2 while it is larger
+    for t in [0.0, 0.2, 0.4, 0.7, 0.8, 1.0, 1.5, 2.0]:
+        resized = app.begin_frame(t)
+        u = app.uniform[0]
+        seq.append((tuple(int(x) for x in u["window"]), int(u["frame"]), int(u["accumulation_frame"]), resized))
+    assert seq[0] == ((400, 225), 1, 0, True)            # 1 + 3*(1-0) = 4 -> window / 4; cold start sees (1, 0)
+    assert seq[1] == ((533, 300), 2, 0, True)            # 3.4 -> 3
+    assert seq[2] == ((800, 450), 3, 0, True)            # 2.8 -> 2 (= screen_fraction)
+    assert seq[3] == ((800, 450), 4, 1, False)           # 1.9 -> 1 < screen_fraction 2: size stable, accumulates
+    assert [s[2] for s in seq[3:]] == [1, 2, 3, 4, 5]
+    assert [s[1] for s in seq] == list(range(1, 9))
+    assert abs(float(app.uniform["aspect"][0]) - 1600 / 900) < 1e-6
+    # invalidation: accumulation_frame is zeroed, then bumped to 1 by the next render unless the resize branch
+    # fires — it does here, because the dynamic fraction jumps back to 4 (src/app.rs:75-76, 87-88)
+    app.invalidate(3.0)
+    assert app.begin_frame(3.0) is True and int(app.uniform["accumulation_frame"][0]) == 0
+    assert tuple(int(x) for x in app.uniform["window"][0]) == (400, 225)
+    # with screen_fraction 4 the size never changes, and the quirk shows: first frame after invalidation has weight 1/2
+    app2 = rt.App(1600, 900, now=0.0)
+    app2.state["screen_fraction"] = 4
+    for t in [0.0, 0.5, 2.0]:
+        app2.begin_frame(t)
+    app2.invalidate(2.5)
+    assert app2.begin_frame(2.6) is False and int(app2.uniform["accumulation_frame"][0]) == 1
+    # accumulate = false pins accumulation_frame to 0
+    app2.state["accumulate"] = 0
+    app2.begin_frame(3.0)
+    assert int(app2.uniform["accumulation_frame"][0]) == 0
+
+
+def test_app_set_params_invalidates_on_hashed_fields_only(rt):
+    app = rt.App(800, 600, now=0.0)
+    for t in [0.0, 1.2, 1.4]:
+        app.begin_frame(t)
+    edited = app.uniform.copy()
+    edited["frame"] = 999                                 # not hashed (src/types.rs:112-121)
+    assert app.set_params(edited, 2.0) is False
+    edited["exposure"] = 1.5
+    assert app.set_params(edited, 2.0) is True and float(app.uniform["exposure"][0]) == 1.5
+    assert int(app.uniform["accumulation_frame"][0]) == 0 and float(app.state["last_invalidation"][0]) == 2.0
+    assert app.set_params(edited, 2.1) is False
+    edited["position"][0] = (3.0, 2.0, 1.0)
+    assert app.set_params(edited, 2.2) is True
