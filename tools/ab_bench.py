@@ -13,6 +13,7 @@ ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--variants", default="0,1")
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--bounces", type=int, default=-1)
 ap.add_argument("--bvh", default="", help="max_leaf,bins builder options")
 ap.add_argument("--tune", default="", help="semicolon-separated weight sets for variant 2, e.g. 4,4,4,4;4,4,2,4")
 args = ap.parse_args()
@@ -31,7 +32,7 @@ if cfg["scene"].startswith("synth:"):
 else:
     ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
 ctx.accum_resize(W, H)
-u = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], max_bounces=cfg["max_bounces"], samples=cfg["samples"],
+u = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], max_bounces=cfg["max_bounces"] if args.bounces < 0 else args.bounces, samples=cfg["samples"],
                     aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]))
 variants = [int(v) for v in args.variants.split(",")]
 times = {v: [] for v in variants}
