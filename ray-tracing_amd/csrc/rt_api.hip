@@ -73,8 +73,9 @@ struct rt_context {
     DevTri *d_tris = nullptr;
     DevShade *d_shade = nullptr;
     DevMaterial *d_materials = nullptr;
-    uint64_t n_nodes = 0, n_tris = 0;
+    uint64_t n_nodes = 0, n_tris = 0, node_bytes = 0;
     uint32_t stack_entries = 1;
+    float scene_abs[3] = {0.0f, 0.0f, 0.0f};
     bool have_scene = false;
     rt_host::Bvh2 bvh;               // kept for refits (rt_models_update)
     uint64_t bvh_prims = 0;
@@ -97,6 +98,7 @@ struct rt_context {
     uint64_t dispatches = 0;
 
     bool opt_count = false, opt_aov = false, opt_cw = false, opt_refit = true;
+    int opt_node_stride = 0;
     int opt_kernel = 2;
     int32_t tune[8] = {4, 4, 2, 4, 64, 0, 0, 0};
     bool timed = false;
@@ -124,25 +126,55 @@ uint64_t local_rows_for(uint32_t h, uint32_t shard_index, uint32_t shard_count) 
 // widened by a few ulp so that a hit the triangle test accepts a hair outside
 // its triangle is not culled by the box (tie policy).
 struct Repacked {
-    std::vector<DevNode> nodes;
+    std::vector<DevNode> nodes;      // node i; uploaded at 16-byte chunk i * node_stride
+    uint32_t node_stride = RT_NODE_CHUNKS;
     std::vector<DevTri> tris;
     std::vector<DevShade> shade;
     uint32_t stack_entries = 1;
+    float scene_abs[3] = {0.0f, 0.0f, 0.0f};   // max |coordinate| of the padded root box
 };
 
 inline float pad_lo(float v) { return v - (fabsf(v) * 4.76837158e-7f + 1e-30f); }
 inline float pad_hi(float v) { return v + (fabsf(v) * 4.76837158e-7f + 1e-30f); }
 
-void set_child(DevNode &n, int which, const rt_host::Aabb &box, int32_t ref) {
-    float lo[3], hi[3];
-    for (int k = 0; k < 3; k++) { lo[k] = pad_lo(box.lo[k]); hi[k] = pad_hi(box.hi[k]); }
-    if (which == 0) {
-        n.lo0x = lo[0]; n.lo0y = lo[1]; n.lo0z = lo[2]; n.hi0x = hi[0]; n.hi0y = hi[1]; n.hi0z = hi[2];
-        n.ref0 = ref;
+// x >= 0 → the f16 bit pattern nearest to x from below (up = false) or above (up = true).
+// Above saturates to +inf, below to 65504; a non-zero upper bound is never an f16
+// denormal, so a flush-to-zero mode cannot shrink a box.
+uint32_t f16_directed(double x, bool up) {
+    if (!(x > 0.0)) return 0u;
+    int e;
+    frexp(x, &e);                         // x = m * 2^e, m in [0.5, 1)
+    const int E = e + 14;                 // biased f16 exponent of a normal number
+    uint32_t bits;
+    if (E >= 31) bits = up ? 0x7c00u : 0x7bffu;
+    else if (E <= 0) {                    // denormal range: units of 2^-24
+        const double q = ldexp(x, 24);
+        bits = (uint32_t)(up ? ceil(q) : floor(q));
     } else {
-        n.lo1x = lo[0]; n.lo1y = lo[1]; n.lo1z = lo[2]; n.hi1x = hi[0]; n.hi1y = hi[1]; n.hi1z = hi[2];
-        n.ref1 = ref;
+        const double q = ldexp(x, 25 - E);            // [1024, 2048)
+        bits = ((uint32_t)(E - 1) << 10) + (uint32_t)(up ? ceil(q) : floor(q));
     }
+    if (up && bits < 0x0400u) bits = 0x0400u;
+    if (bits > 0x7c00u) bits = 0x7c00u;
+    return bits;
+}
+
+// Both children of one node: padded boxes → lower corner + outward-rounded f16 offsets.
+void set_children(DevNode &n, const rt_host::Aabb &box0, int32_t ref0, const rt_host::Aabb &box1, int32_t ref1) {
+    float lo0[3], hi0[3], lo1[3], hi1[3], lo[3];
+    for (int k = 0; k < 3; k++) {
+        lo0[k] = pad_lo(box0.lo[k]); hi0[k] = pad_hi(box0.hi[k]);
+        lo1[k] = pad_lo(box1.lo[k]); hi1[k] = pad_hi(box1.hi[k]);
+        lo[k] = lo0[k] < lo1[k] ? lo0[k] : lo1[k];
+    }
+    auto pack = [&](const float *clo, const float *chi, int k) {
+        return (f16_directed((double)chi[k] - (double)lo[k], true) << 16) | f16_directed((double)clo[k] - (double)lo[k], false);
+    };
+    n.lox = lo[0]; n.loy = lo[1]; n.loz = lo[2];
+    n.c0x = pack(lo0, hi0, 0); n.c0y = pack(lo0, hi0, 1); n.c0z = pack(lo0, hi0, 2);
+    n.c1x = pack(lo1, hi1, 0); n.c1y = pack(lo1, hi1, 1); n.c1z = pack(lo1, hi1, 2);
+    n.ref0 = ref0; n.ref1 = ref1;
+    n.pad = 0;
 }
 
 void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const std::vector<uint32_t> &ids,
@@ -194,14 +226,17 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
 
     auto leaf_ref = [&](const rt_host::Bvh2Node &n) { return dev_leaf_ref(n.left, n.count); };
     const rt_host::Bvh2Node &root = bvh.nodes[0];
+    for (int k = 0; k < 3 && n_tris; k++) {
+        const float m = fmaxf(fabsf(pad_lo(root.box.lo[k])), fabsf(pad_hi(root.box.hi[k])));
+        out.scene_abs[k] = m <= 3.0e38f ? m : 3.0e38f;   // non-finite coordinates: every box test passes, still correct
+    }
     if (root.count > 0 || bvh.nodes.size() == 1) {
         // the whole scene is one leaf (or empty): a root whose second child is empty
         out.nodes.resize(1);
         memset(&out.nodes[0], 0, sizeof(DevNode));
         rt_host::Aabb box = root.box;
         if (n_tris == 0) for (int k = 0; k < 3; k++) { box.lo[k] = 0.0f; box.hi[k] = 0.0f; }
-        set_child(out.nodes[0], 0, box, dev_leaf_ref(root.left, n_tris ? root.count : 0));
-        set_child(out.nodes[0], 1, box, dev_leaf_ref(0, 0));
+        set_children(out.nodes[0], box, dev_leaf_ref(root.left, n_tris ? root.count : 0), box, dev_leaf_ref(0, 0));
         out.stack_entries = 2;
         return;
     }
@@ -222,10 +257,9 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         const rt_host::Bvh2Node &c0 = bvh.nodes[n.left], &c1 = bvh.nodes[n.left + 1];
         int32_t r0, r1;
         uint32_t d0 = 0, d1 = 0;
-        if (c0.count) r0 = leaf_ref(c0); else { d0 = next++; r0 = (int32_t)d0; }
-        if (c1.count) r1 = leaf_ref(c1); else { d1 = next++; r1 = (int32_t)d1; }
-        set_child(d, 0, c0.box, r0);
-        set_child(d, 1, c1.box, r1);
+        if (c0.count) r0 = leaf_ref(c0); else { d0 = next++; r0 = (int32_t)(d0 * out.node_stride); }
+        if (c1.count) r1 = leaf_ref(c1); else { d1 = next++; r1 = (int32_t)(d1 * out.node_stride); }
+        set_children(d, c0.box, r0, c1.box, r1);
         if (!c1.count) todo.push_back({n.left + 1, d1});
         if (!c0.count) todo.push_back({n.left, d0});
     }
@@ -283,7 +317,11 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
         ctx->bvh_prims = n_prims;
         ctx->rebuilds++;
     }
+    if (bvh.nodes.size() * 4ull >= (1ull << 31)) return fail(RT_ERR_INVALID_ARGUMENT, "scene: BVH has too many nodes");
     Repacked rp;
+    // Node stride: 48 B (default) packs the tree tightest; 64 B keeps every node inside one 64-B memory sector.
+    // Measured: 48 B is 1.5 % faster on C3 (cache-resident), no difference on C4 (2 GB of records).
+    rp.node_stride = ctx->opt_node_stride ? (uint32_t)ctx->opt_node_stride : (uint32_t)RT_NODE_CHUNKS;
     repack(bvh, corners, ids, *ctx, rp);
     ctx->build_seconds = bvh.build_seconds;
 
@@ -306,17 +344,26 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
-    RT_HIP(hipMalloc((void **)&ctx->d_nodes, rp.nodes.size() * sizeof(DevNode)));
+    const size_t node_bytes = rp.nodes.size() * (size_t)rp.node_stride * 16u;
+    RT_HIP(hipMalloc((void **)&ctx->d_nodes, node_bytes));
     RT_HIP(hipMalloc((void **)&ctx->d_tris, rp.tris.size() * sizeof(DevTri)));
     RT_HIP(hipMalloc((void **)&ctx->d_shade, rp.shade.size() * sizeof(DevShade)));
     RT_HIP(hipMalloc((void **)&ctx->d_materials, mats.size() * sizeof(DevMaterial)));
-    RT_HIP(hipMemcpy(ctx->d_nodes, rp.nodes.data(), rp.nodes.size() * sizeof(DevNode), hipMemcpyHostToDevice));
+    if (rp.node_stride == RT_NODE_CHUNKS) {
+        RT_HIP(hipMemcpy(ctx->d_nodes, rp.nodes.data(), node_bytes, hipMemcpyHostToDevice));
+    } else {
+        RT_HIP(hipMemset(ctx->d_nodes, 0, node_bytes));
+        RT_HIP(hipMemcpy2D(ctx->d_nodes, (size_t)rp.node_stride * 16u, rp.nodes.data(), sizeof(DevNode), sizeof(DevNode), rp.nodes.size(),
+                           hipMemcpyHostToDevice));
+    }
+    ctx->node_bytes = node_bytes;
     RT_HIP(hipMemcpy(ctx->d_tris, rp.tris.data(), rp.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_shade, rp.shade.data(), rp.shade.size() * sizeof(DevShade), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
     ctx->n_nodes = rp.nodes.size();
     ctx->n_tris = n_prims;
     ctx->stack_entries = rp.stack_entries;
+    memcpy(ctx->scene_abs, rp.scene_abs, sizeof(ctx->scene_abs));
     ctx->persistent_blocks = 0;
     ctx->have_scene = true;
     return RT_OK;
@@ -372,6 +419,7 @@ int launch(rt_context *ctx, const RtUniform &u) {
     float sh, ch;
     rt_sincos(u.camera.fov * 0.5f, &sh, &ch);
     P.fov_scale = sh / ch;
+    memcpy(P.scene_abs, ctx->scene_abs, sizeof(P.scene_abs));
     P.aspect = u.camera.aspect;
     P.forward[0] = forward.x; P.forward[1] = forward.y; P.forward[2] = forward.z;
     P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
@@ -463,6 +511,10 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
         case RT_OPT_KERNEL: ctx->opt_kernel = (int)value; return RT_OK;
         case RT_OPT_FRONT_FACE_CW: ctx->opt_cw = value != 0; return RT_OK;
         case RT_OPT_REFIT: ctx->opt_refit = value != 0; return RT_OK;
+        case RT_OPT_NODE_STRIDE:
+            if (value != 0 && value != 3 && value != 4) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_STRIDE: 0 (auto), 3 or 4");
+            ctx->opt_node_stride = value;
+            return RT_OK;
         default:
             if (key >= 100 && key < 108) { ctx->tune[key - 100] = (int32_t)value; return RT_OK; }
             return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);
@@ -655,7 +707,7 @@ int rt_stats(rt_context *ctx, RtStats *out) {
     out->wave_steps = c.wave_steps;
     out->dispatches = ctx->dispatches;
     out->bvh_nodes = ctx->n_nodes;
-    out->bvh_bytes = ctx->n_nodes * sizeof(DevNode) + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));
+    out->bvh_bytes = ctx->node_bytes + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));
     out->bvh_build_seconds = ctx->build_seconds;
     out->bvh_refits = ctx->refits;
     out->bvh_rebuilds = ctx->rebuilds;

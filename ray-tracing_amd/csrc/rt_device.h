@@ -5,9 +5,9 @@
 // repacks everything once per scene upload into 16-byte-aligned records that a
 // lane fetches with a few dwordx4 loads:
 //
-//   DevNode   64 B  one BVH2 inner node holding BOTH children's boxes and
-//                   references, so one visit = one 64-B fetch (half a 128-B
-//                   L2 line) and decides both children;
+//   DevNode   48 B  one BVH2 inner node holding BOTH children's boxes and
+//                   references, so one visit = three 16-B fetches and decides
+//                   both children;
 //   DevTri    48 B  corner + two edge vectors in leaf order + global id;
 //   DevShade 128 B  everything trace_ray's attribute part needs
 //                   (shaders/main.wgsl:86-101) for one triangle, one L2 line,
@@ -16,18 +16,23 @@
 #pragma once
 #include <stdint.h>
 
-// Field order pairs the planes so that the slab test is six packed FMAs
-// (v_pk_fma_f32) against the constant pairs (ix,iy), (iz,ix), (iy,iz).
+// One lane reads a node with three dwordx4 loads.  Child boxes are stored as f16
+// OFFSETS from the node's own lower corner (lo), rounded outward, so the slab
+// test feeds them straight into v_fma_mix_f32 (f16 source, f32 result):
+//   base_k = lo_k * inv_k - o_k * inv_k        3 FMAs per node
+//   t      = off * inv_k + base_k              12 mixed FMAs, no unpacking
+// The rounding error of an offset is <= 2^-11 of the PARENT's extent, i.e. the
+// boxes grow by a fraction of a percent, never shrink.
 struct alignas(16) DevNode {
-    float lo0x, lo0y, lo0z, hi0x;   // child 0 box
-    float hi0y, hi0z, lo1x, lo1y;   // child 0 box / child 1 box
-    float lo1z, hi1x, hi1y, hi1z;   // child 1 box
-    int32_t ref0, ref1;             // child references
-    uint32_t pad0, pad1;
+    float lox, loy, loz; int32_t ref0;          // lower corner of (child 0 U child 1); child 0 reference
+    uint32_t c0x, c0y, c0z; int32_t ref1;       // child 0, per axis: (hi_offset_f16 << 16) | lo_offset_f16; child 1 reference
+    uint32_t c1x, c1y, c1z; uint32_t pad;       // child 1
 };
-static_assert(sizeof(DevNode) == 64, "DevNode");
+static_assert(sizeof(DevNode) == 48, "DevNode");
+#define RT_NODE_CHUNKS 3                        // 16-byte chunks per node
 
-// Child reference: >= 0 → index of an inner DevNode; < 0 → leaf, with
+// Child reference: >= 0 → inner DevNode, as its index * RT_NODE_CHUNKS (a
+// float4 index: the address needs a shift only); < 0 → leaf, with
 // ~ref = (first_slot << 3) | count, count in 0..7 (0 = empty child).
 static inline int32_t dev_leaf_ref(uint32_t first_slot, uint32_t count) {
     return (int32_t)~((first_slot << 3) | count);
@@ -104,5 +109,6 @@ struct RenderParams {
     float cam_pos[3];
     float forward[3], right[3], up[3];   // ray_direction's basis (shaders/ray.wgsl:2-4), hoisted to the host
     float aspect, fov_scale;             // ctx.camera.aspect, tan(fov/2) (shaders/ray.wgsl:6-7)
+    float scene_abs[3];                  // max |coordinate| of the BVH root box per axis (slab-test error bound)
     int32_t tune[8];                     // scheduler tunables (experiments)
 };

@@ -115,39 +115,51 @@ __device__ __forceinline__ void intersect_leaf(const DevTri *__restrict__ tris, 
     }
 }
 
-// Slab-test constants of one ray (outside the arithmetic contract; conservative):
-//   t = plane * inv - o * inv as one FMA.  inv comes from v_rcp_f32 (1 ulp); a zero
-//   direction component is nudged to 1e-30 so no inf/NaN appears.  The error of t is
-//   <= 2^-24 |o*inv| + 2^-22 |t|, covered by eps (absolute) and the 1.000001 factor.
+// Slab-test constants of one ray (outside the arithmetic contract; conservative).
+// A node stores its lower corner `lo` in f32 and the child planes as f16 offsets
+// from it (rt_device.h), rounded outward, so per axis
+//   base = lo * inv - o * inv          (one FMA per axis per node)
+//   t    = off * inv + base            (one v_fma_mix_f32 per plane)
+// inv comes from v_rcp_f32 (1 ulp); a zero direction component is nudged to 1e-30
+// so no inf/NaN appears.  Error of t: relative 2^-22 |t| from inv and the last
+// rounding (covered by the 1.000001 factor), absolute <= 2^-24 (2|o| + |lo|) |inv|
+// from o*inv and base, covered by eps = 2^-21 max_k (|o_k| + R_k) |inv_k| with
+// R_k = max |coordinate| of the root box (RenderParams::scene_abs).
+typedef _Float16 rt_h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float lo16(uint32_t w) { return (float)__builtin_bit_cast(rt_h2, w).x; }
+__device__ __forceinline__ float hi16(uint32_t w) { return (float)__builtin_bit_cast(rt_h2, w).y; }
+__device__ __forceinline__ uint4 ld4u(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
+
 struct Slab {
-    f2 ixy, izx, iyz, oxy, ozx, oyz;
-    float eps;
+    float ix, iy, iz, ox, oy, oz, eps;
 };
-__device__ __forceinline__ Slab make_slab(rt_v3 o, rt_v3 d) {
+__device__ __forceinline__ Slab make_slab(const RenderParams &P, rt_v3 o, rt_v3 d) {
     auto nz = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x; };
-    const float ix = __builtin_amdgcn_rcpf(nz(d.x)), iy = __builtin_amdgcn_rcpf(nz(d.y)), iz = __builtin_amdgcn_rcpf(nz(d.z));
-    const float ox = -(o.x * ix), oy = -(o.y * iy), oz = -(o.z * iz);
     Slab s;
-    s.eps = 4.76837158e-7f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
-    s.ixy = mk2(ix, iy); s.izx = mk2(iz, ix); s.iyz = mk2(iy, iz);
-    s.oxy = mk2(ox, oy); s.ozx = mk2(oz, ox); s.oyz = mk2(oy, oz);
+    s.ix = __builtin_amdgcn_rcpf(nz(d.x)); s.iy = __builtin_amdgcn_rcpf(nz(d.y)); s.iz = __builtin_amdgcn_rcpf(nz(d.z));
+    s.ox = -(o.x * s.ix); s.oy = -(o.y * s.iy); s.oz = -(o.z * s.iz);
+    s.eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(s.ix), fabsf(s.ox)), fmaf(P.scene_abs[1], fabsf(s.iy), fabsf(s.oy))),
+                                   fmaf(P.scene_abs[2], fabsf(s.iz), fabsf(s.oz)));
     return s;
 }
-// both children of one node: entry distances n0/n1 and hit flags
-__device__ __forceinline__ void test_node(const DevNode *n, const Slab &sl, float tbest, bool &h0, bool &h1, float &n0,
+// both children of one node: entry distances n0/n1, hit flags, references
+__device__ __forceinline__ void test_node(const float4 *n, const Slab &sl, float tbest, bool &h0, bool &h1, float &n0,
                                           float &n1, int2 &refs) {
-    float4 a = ld4(&n->lo0x), b = ld4(&n->hi0y), c = ld4(&n->lo1z);
-    refs = *reinterpret_cast<const int2 *>(&n->ref0);
-    f2 t0 = __builtin_elementwise_fma(mk2(a.x, a.y), sl.ixy, sl.oxy);   // child 0: lo.x lo.y
-    f2 t1 = __builtin_elementwise_fma(mk2(a.z, a.w), sl.izx, sl.ozx);   //          lo.z hi.x
-    f2 t2 = __builtin_elementwise_fma(mk2(b.x, b.y), sl.iyz, sl.oyz);   //          hi.y hi.z
-    f2 s0 = __builtin_elementwise_fma(mk2(b.z, b.w), sl.ixy, sl.oxy);   // child 1: lo.x lo.y
-    f2 s1 = __builtin_elementwise_fma(mk2(c.x, c.y), sl.izx, sl.ozx);   //          lo.z hi.x
-    f2 s2 = __builtin_elementwise_fma(mk2(c.z, c.w), sl.iyz, sl.oyz);   //          hi.y hi.z
-    n0 = fmaxf(fmaxf(fminf(t0.x, t1.y), fminf(t0.y, t2.x)), fmaxf(fminf(t1.x, t2.y), kTMin));
-    float f0 = fminf(fminf(fmaxf(t0.x, t1.y), fmaxf(t0.y, t2.x)), fminf(fmaxf(t1.x, t2.y), tbest));
-    n1 = fmaxf(fmaxf(fminf(s0.x, s1.y), fminf(s0.y, s2.x)), fmaxf(fminf(s1.x, s2.y), kTMin));
-    float f1 = fminf(fminf(fmaxf(s0.x, s1.y), fmaxf(s0.y, s2.x)), fminf(fmaxf(s1.x, s2.y), tbest));
+    const float4 a = ld4(n);
+    const uint4 b = ld4u(n + 1), c = ld4u(n + 2);
+    refs.x = __float_as_int(a.w);
+    refs.y = (int32_t)b.w;
+    const float bx = fmaf(a.x, sl.ix, sl.ox), by = fmaf(a.y, sl.iy, sl.oy), bz = fmaf(a.z, sl.iz, sl.oz);
+    const float t0x = fmaf(lo16(b.x), sl.ix, bx), t1x = fmaf(hi16(b.x), sl.ix, bx);
+    const float t0y = fmaf(lo16(b.y), sl.iy, by), t1y = fmaf(hi16(b.y), sl.iy, by);
+    const float t0z = fmaf(lo16(b.z), sl.iz, bz), t1z = fmaf(hi16(b.z), sl.iz, bz);
+    const float s0x = fmaf(lo16(c.x), sl.ix, bx), s1x = fmaf(hi16(c.x), sl.ix, bx);
+    const float s0y = fmaf(lo16(c.y), sl.iy, by), s1y = fmaf(hi16(c.y), sl.iy, by);
+    const float s0z = fmaf(lo16(c.z), sl.iz, bz), s1z = fmaf(hi16(c.z), sl.iz, bz);
+    n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
+    const float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tbest));
+    n1 = fmaxf(fmaxf(fminf(s0x, s1x), fminf(s0y, s1y)), fmaxf(fminf(s0z, s1z), kTMin));
+    const float f1 = fminf(fminf(fmaxf(s0x, s1x), fmaxf(s0y, s1y)), fminf(fmaxf(s0z, s1z), tbest));
     h0 = n0 <= fmaf(f0, 1.000001f, sl.eps);
     h1 = n1 <= fmaf(f1, 1.000001f, sl.eps);
 }
@@ -160,8 +172,8 @@ __device__ __forceinline__ Hit trace(const RenderParams &P, uint32_t *__restrict
     const bool cull = (P.flags & 1u) != 0;   // flags = 0x10 * (ctx.flags & 1), main.wgsl:76
     const bool cw = P.front_face_cw != 0;
 
-    const Slab sl = make_slab(o, d);
-    const DevNode *__restrict__ nodes = P.nodes;
+    const Slab sl = make_slab(P, o, d);
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(P.nodes);
 
     int sp = 0;
     int32_t cur = 0;   // root is always an inner node
@@ -537,7 +549,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     const Camera C = load_camera(P);
     const bool cull = (P.flags & 1u) != 0;
     const bool cw = P.front_face_cw != 0;
-    const DevNode *__restrict__ nodes = P.nodes;
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(P.nodes);
     Tally tl;
     PixelState S;
     Hit best;
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0, eps = 0;
     int phase = PH_FETCH;
     bool have_pixel = false;  // FETCH: a finished pixel-frame waits to be written out
-    int32_t cur = 0;          // NODE: inner node index; LEAF: leaf reference (< 0)
+    int32_t cur = 0;          // NODE: inner node reference (float4 index); LEAF: leaf reference (< 0)
     uint32_t leaf_pos = 0;    // LEAF: triangles of the leaf already tested
     int sp = 0;
     uint32_t w_next = 0, w_end = 0;   // the wave's claimed chunk, wave-uniform
@@ -558,7 +570,8 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
         auto nz = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x; };
         ix = __builtin_amdgcn_rcpf(nz(S.dir.x)); iy = __builtin_amdgcn_rcpf(nz(S.dir.y)); iz = __builtin_amdgcn_rcpf(nz(S.dir.z));
         ox = -(S.pos.x * ix); oy = -(S.pos.y * iy); oz = -(S.pos.z * iz);
-        eps = 4.76837158e-7f * fmaxf(fmaxf(fabsf(ox), fabsf(oy)), fabsf(oz));
+        eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(ox)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(oy))),
+                                     fmaf(P.scene_abs[2], fabsf(iz), fabsf(oz)));   // see make_slab
         best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
         cur = 0; sp = 0; leaf_pos = 0;
         phase = PH_NODE;
@@ -589,13 +602,17 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
               for (int rep = 0; rep < RT_NODE_REPS; rep++)
                 if (phase == PH_NODE) {
                     if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
-                    const DevNode *n = nodes + cur;
-                    float4 a = ld4(&n->lo0x), b = ld4(&n->hi0y), c = ld4(&n->lo1z);
-                    int2 refs = *reinterpret_cast<const int2 *>(&n->ref0);
-                    float t0x = fmaf(a.x, ix, ox), t0y = fmaf(a.y, iy, oy), t0z = fmaf(a.z, iz, oz);
-                    float t1x = fmaf(a.w, ix, ox), t1y = fmaf(b.x, iy, oy), t1z = fmaf(b.y, iz, oz);
-                    float s0x = fmaf(b.z, ix, ox), s0y = fmaf(b.w, iy, oy), s0z = fmaf(c.x, iz, oz);
-                    float s1x = fmaf(c.y, ix, ox), s1y = fmaf(c.z, iy, oy), s1z = fmaf(c.w, iz, oz);
+                    const float4 *n = nodes + cur;
+                    const float4 a = ld4(n);
+                    const uint4 b = ld4u(n + 1), c = ld4u(n + 2);
+                    const int2 refs = make_int2(__float_as_int(a.w), (int32_t)b.w);
+                    const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
+                    float t0x = fmaf(lo16(b.x), ix, bx), t1x = fmaf(hi16(b.x), ix, bx);
+                    float t0y = fmaf(lo16(b.y), iy, by), t1y = fmaf(hi16(b.y), iy, by);
+                    float t0z = fmaf(lo16(b.z), iz, bz), t1z = fmaf(hi16(b.z), iz, bz);
+                    float s0x = fmaf(lo16(c.x), ix, bx), s1x = fmaf(hi16(c.x), ix, bx);
+                    float s0y = fmaf(lo16(c.y), iy, by), s1y = fmaf(hi16(c.y), iy, by);
+                    float s0z = fmaf(lo16(c.z), iz, bz), s1z = fmaf(hi16(c.z), iz, bz);
                     float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
                     float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
                     float n1 = fmaxf(fmaxf(fminf(s0x, s1x), fminf(s0y, s1y)), fmaxf(fminf(s0z, s1z), kTMin));

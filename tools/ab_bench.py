@@ -15,23 +15,30 @@ ap.add_argument("--variants", default="0,1")
 ap.add_argument("--count", action="store_true")
 ap.add_argument("--bounces", type=int, default=-1)
 ap.add_argument("--bvh", default="", help="max_leaf,bins builder options")
+ap.add_argument("--stride", default="", help="comma-separated node strides (3,4): one context each, variant 2, interleaved")
 ap.add_argument("--tune", default="", help="semicolon-separated weight sets for variant 2, e.g. 4,4,4,4;4,4,2,4")
 args = ap.parse_args()
 rt = graft.load_package()
 cfg = graft.load_config(args.config)
 W, H = int(cfg["width"] * args.scale), int(cfg["height"] * args.scale)
-ctx = rt.Context(0)
-if args.bvh:
-    ml, bins = (int(x) for x in args.bvh.split(","))
-    ctx.set_option(106, ml); ctx.set_option(107, bins)
+syn = None
 if cfg["scene"].startswith("synth:"):
     from ray_tracing_amd import synth
     syn = synth.load_config_scene(cfg, ROOT)
-    ctx.scene_upload(syn.vertices, syn.indices, syn.primitives, syn.models)
-    if len(syn.spheres): ctx.spheres_upload(syn.spheres)
-else:
-    ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
-ctx.accum_resize(W, H)
+def make_ctx(stride=0):
+    ctx = rt.Context(0)
+    if args.bvh:
+        ml, bins = (int(x) for x in args.bvh.split(","))
+        ctx.set_option(106, ml); ctx.set_option(107, bins)
+    ctx.set_option(rt.RT_OPT_NODE_STRIDE, stride)
+    if syn is not None:
+        ctx.scene_upload(syn.vertices, syn.indices, syn.primitives, syn.models)
+        if len(syn.spheres): ctx.spheres_upload(syn.spheres)
+    else:
+        ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
+    ctx.accum_resize(W, H)
+    return ctx
+ctx = make_ctx()
 u = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], max_bounces=cfg["max_bounces"] if args.bounces < 0 else args.bounces, samples=cfg["samples"],
                     aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]))
 variants = [int(v) for v in args.variants.split(",")]
@@ -53,6 +60,17 @@ for r in range(args.rounds + 1):
 for v in variants:
     t = np.array(times[v])
     print(f"variant {v}: median {np.median(t):.3f} ms  min {t.min():.3f}  -> {st.rays / np.median(t) / 1e3:.0f} Mrays/s")
+if args.stride:
+    strides = [int(x) for x in args.stride.split(",")]
+    ctxs = {sd: make_ctx(sd) for sd in strides}
+    res = {sd: [] for sd in strides}
+    for r in range(args.rounds + 1):
+        for sd in strides:
+            ctxs[sd].dispatch(u)
+            ms = ctxs[sd].last_dispatch_ms()
+            if r > 0: res[sd].append(ms)
+    for sd in strides:
+        print(f"node stride {sd * 16} B: median {np.median(res[sd]):.3f} ms min {min(res[sd]):.3f}")
 if args.tune:
     ctx.set_option(rt.RT_OPT_KERNEL, 2)
     sets = [[int(x) for x in t.split(",")] for t in args.tune.split(";")]
