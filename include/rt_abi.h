@@ -174,6 +174,8 @@ typedef struct RtStats {
 #define RT_OPT_FRONT_FACE_CW   4   /* 0 (default): CCW = front; 1: CW = front */
 #define RT_OPT_REFIT           5   /* 1 (default): rt_models_update refits the BVH (≙ acceleration_structure.update(),
                                       src/app.rs:61); 0: full rebuild */
+#define RT_OPT_FRAME_PIPELINE  7   /* 1 (default): rt_dispatch_frames renders its frames in one launch, frames of
+                                      different pixels overlapping (same bits as frame-by-frame); 0: one launch per frame */
 #define RT_OPT_NODE_STRIDE     6   /* BVH node stride in 16-byte units for the NEXT scene upload: 3 (48 B, tightest),
                                       4 (64 B, one memory sector per node) or 0 (default = 3) */
 

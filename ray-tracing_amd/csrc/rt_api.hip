@@ -101,6 +101,10 @@ struct rt_context {
     int opt_node_stride = 0;
     int opt_kernel = 2;
     int32_t tune[8] = {4, 4, 2, 4, 64, 0, 0, 0};
+    float4 *d_stage = nullptr;       // per-frame tone-mapped colours of a multi-frame launch (lazy, grows)
+    uint64_t stage_elems = 0;
+    int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
+    uint32_t chunk = 64;             // queue grain: small enough that the last chunk is not a long tail
     bool timed = false;
 };
 
@@ -389,9 +393,24 @@ int ensure_aov(rt_context *ctx) {
     return RT_OK;
 }
 
-int launch(rt_context *ctx, const RtUniform &u) {
+int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
     RenderParams P;
     memset(&P, 0, sizeof P);
+    P.n_frames = n_frames;
+    P.local_rows = (uint32_t)local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count);
+    if (n_frames > 1) {
+        const uint64_t stride = (uint64_t)P.local_rows * ctx->width;
+        const uint64_t need = (stride ? stride : 1) * n_frames;
+        if (ctx->stage_elems < need) {
+            RT_HIP(hipStreamSynchronize(ctx->stream));
+            dev_free(ctx->d_stage);
+            ctx->stage_elems = 0;
+            RT_HIP(hipMalloc((void **)&ctx->d_stage, need * sizeof(float4)));
+            ctx->stage_elems = need;
+        }
+        P.stage = ctx->d_stage;
+        P.stage_stride = stride;
+    }
     P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
     P.textures = ctx->d_textures; P.texels = ctx->d_texels; P.n_textures = ctx->n_textures;
     P.accum = ctx->d_accum;
@@ -426,12 +445,13 @@ int launch(rt_context *ctx, const RtUniform &u) {
     P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
     P.queue = ctx->d_queue;
     memcpy(P.tune, ctx->tune, sizeof P.tune);
+    P.chunk = ctx->chunk;
     if (ctx->opt_kernel != 1) {
         RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
         if (ctx->persistent_blocks == 0) ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries);
     }
     RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->spheres.empty() || ctx->n_textures > 0, ctx->persistent_blocks, ctx->stream));
-    ctx->dispatches++;
+    ctx->dispatches += n_frames;
     return RT_OK;
 }
 
@@ -486,7 +506,7 @@ int rt_destroy(rt_context *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
     if (ctx->accum_owned) dev_free(ctx->d_accum);
-    dev_free(ctx->d_aov); dev_free(ctx->d_counters); dev_free(ctx->d_queue);
+    dev_free(ctx->d_aov); dev_free(ctx->d_counters); dev_free(ctx->d_queue); dev_free(ctx->d_stage);
     dev_free(ctx->d_textures); dev_free(ctx->d_texels);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -511,12 +531,14 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
         case RT_OPT_KERNEL: ctx->opt_kernel = (int)value; return RT_OK;
         case RT_OPT_FRONT_FACE_CW: ctx->opt_cw = value != 0; return RT_OK;
         case RT_OPT_REFIT: ctx->opt_refit = value != 0; return RT_OK;
+        case RT_OPT_FRAME_PIPELINE: ctx->opt_pipeline = value != 0; return RT_OK;
         case RT_OPT_NODE_STRIDE:
             if (value != 0 && value != 3 && value != 4) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_STRIDE: 0 (auto), 3 or 4");
             ctx->opt_node_stride = value;
             return RT_OK;
         default:
             if (key >= 100 && key < 108) { ctx->tune[key - 100] = (int32_t)value; return RT_OK; }
+            if (key == 108 && value >= 1 && value <= 65536) { ctx->chunk = (uint32_t)value; return RT_OK; }
             return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);
     }
 }
@@ -649,15 +671,31 @@ int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames) {
     int r = check_dispatch(ctx, uniform);
     if (r) return r;
     RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    for (uint32_t i = 0; i < n_frames; i++) {
+    // The phased kernel takes a run of frames in ONE launch (frame-major work queue, per-pixel ordering flags):
+    // the slow tail of a frame, where the last long pixels run on a nearly empty GPU, overlaps the next frame.
+    const uint64_t frame_slots = (uint64_t)((ctx->width + 7u) / 8u) * ctx->local_bands * 64u;
+    uint32_t group_max = 1;
+    if (ctx->opt_pipeline && ctx->opt_kernel == 2 && !ctx->opt_aov && ctx->width < 65536u && frame_slots > 0) {
+        const uint64_t by_queue = 0xFFFFFFFFull / frame_slots;                       // 32-bit work-queue index
+        const uint64_t by_stage = (4ull << 30) / (frame_slots * sizeof(float4));      // <= 4 GiB of staging
+        const uint64_t cap = by_queue < by_stage ? by_queue : by_stage;
+        group_max = (uint32_t)(cap < 65535u ? cap : 65535u);
+        if (group_max == 0) group_max = 1;
+    }
+    uint32_t i = 0;
+    while (i < n_frames) {
+        const uint32_t group = (n_frames - i < group_max) ? n_frames - i : group_max;
         uniform->accumulation_frame += 1;                  // src/app.rs:78
         if (ctx->accum_fresh) {                            // src/app.rs:87-88
             uniform->accumulation_frame = 0;
             ctx->accum_fresh = false;
         }
         uniform->frame += 1;                               // src/app.rs:96
-        r = launch(ctx, *uniform);
+        r = launch(ctx, *uniform, group);
         if (r) return r;
+        uniform->accumulation_frame += group - 1;          // the launch covered frames frame .. frame + group - 1
+        uniform->frame += group - 1;
+        i += group;
     }
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;

@@ -39,7 +39,6 @@ constexpr int kBlock = 256;                  // 4 waves per workgroup
 #ifndef RT_PHASED_WAVES
 #define RT_PHASED_WAVES 5                    // waves per SIMD the phased kernel is register-budgeted for
 #endif
-constexpr uint32_t kChunk = 256;             // pixel slots a wave claims per atomic (4 tiles)
 constexpr float kTMin = 0.001f;              // main.wgsl:77
 constexpr float kTMax = 3.40282347e+38f;     // main.wgsl:77
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
@@ -263,7 +262,7 @@ __device__ __forceinline__ float tone_map1(float x) {
 
 // One pixel-frame in flight on a lane.
 struct PixelState {
-    uint32_t x, local_row;      // where the result goes
+    uint32_t xf, local_row;     // where the result goes: x | frame_offset << 16 (frame of a multi-frame launch)
     float px, py;               // `pos` of main.wgsl:21
     uint32_t seed;
     uint32_t sample, bounce;
@@ -271,6 +270,10 @@ struct PixelState {
     rt_v3 light, color, pos, dir;
     bool first_ray;
 };
+
+// a launch of one frame (any width) keeps x whole; multi-frame launches need width < 65536 (checked by the host)
+__device__ __forceinline__ uint32_t pixel_x(const RenderParams &P, const PixelState &S) { return P.n_frames > 1u ? (S.xf & 0xffffu) : S.xf; }
+__device__ __forceinline__ uint32_t pixel_frame(const RenderParams &P, const PixelState &S) { return P.n_frames > 1u ? (S.xf >> 16) : 0u; }
 
 struct Camera {
     rt_v3 cam, forward, right, up;
@@ -292,13 +295,13 @@ __device__ __forceinline__ void new_path(const RenderParams &P, const Camera &C,
 
 // main.wgsl:17-25 for pixel (x, y)
 __device__ __forceinline__ void begin_pixel(const RenderParams &P, const Camera &C, PixelState &S, uint32_t x, uint32_t y,
-                                            uint32_t local_row) {
-    S.x = x;
+                                            uint32_t local_row, uint32_t frame_off = 0) {
+    S.xf = x | (frame_off << 16);
     S.local_row = local_row;
     const uint32_t pixel_idx = y * P.width + x;
     S.px = (float)x / C.Wf - 0.5f;                     // main.wgsl:20-21
     S.py = (1.0f - (float)y / C.Hf) - 0.5f;
-    S.seed = rt_seed(pixel_idx, P.frame);              // main.wgsl:23
+    S.seed = rt_seed(pixel_idx, P.frame + frame_off);  // main.wgsl:23
     S.total = v3(0.0f, 0.0f, 0.0f);
     S.sample = 0;
     S.first_ray = true;
@@ -309,8 +312,15 @@ __device__ __forceinline__ void finish_pixel(const RenderParams &P, const PixelS
     const float ns = (float)P.samples;
     rt_v3 total = v3(S.total.x / ns, S.total.y / ns, S.total.z / ns);
     rt_v3 mapped = v3(tone_map1(total.x * P.exposure), tone_map1(total.y * P.exposure), tone_map1(total.z * P.exposure));
+    const size_t pix = (size_t)S.local_row * P.width + pixel_x(P, S);
+    if (P.n_frames > 1u) {
+        // multi-frame launch: frames of a pixel finish in any order, so the tone-mapped colour is parked
+        // per frame and rt_blend_frames applies main.wgsl:31-32 to them in frame order afterwards
+        P.stage[(size_t)pixel_frame(P, S) * P.stage_stride + pix] = make_float4(mapped.x, mapped.y, mapped.z, 0.0f);
+        return;
+    }
     const float w = 1.0f / (float)(P.accumulation_frame + 1u);
-    float4 *dst = reinterpret_cast<float4 *>(P.accum) + (size_t)S.local_row * P.width + S.x;
+    float4 *dst = reinterpret_cast<float4 *>(P.accum) + pix;
     float4 old = *dst;
     rt_v3 out = rt_mix(v3(old.x, old.y, old.z), mapped, w);
     *dst = make_float4(out.x, out.y, out.z, old.w);
@@ -324,7 +334,7 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
     if (AOV && S.first_ray) {
         uint32_t g = kNoHit, pr = kNoHit;
         if (h.slot != kNoHit) { g = P.shade[h.slot].geometry; pr = P.shade[h.slot].primitive; }
-        uint2 *dst = reinterpret_cast<uint2 *>(P.aov) + (size_t)S.local_row * P.width + S.x;
+        uint2 *dst = reinterpret_cast<uint2 *>(P.aov) + (size_t)S.local_row * P.width + pixel_x(P, S);
         *dst = make_uint2(g, pr);
     }
     S.first_ray = false;
@@ -495,11 +505,11 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
             if (w_next == w_end) {
                 if (drained) break;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&P.queue->head, kChunk);
+                if (lane == 0) base = atomicAdd(&P.queue->head, P.chunk);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base >= total_slots) { drained = true; break; }
                 w_next = base;
-                w_end = min(base + kChunk, total_slots);
+                w_end = min(base + P.chunk, total_slots);
             }
             const uint32_t avail = w_end - w_next;
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -545,7 +555,8 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t total_slots = P.tiles_x * P.local_bands * 64u;
+    const uint32_t frame_slots = P.tiles_x * P.local_bands * 64u;
+    const uint32_t total_slots = frame_slots * P.n_frames;    // work items: frame-major (host keeps this below 2^32)
     const Camera C = load_camera(P);
     const bool cull = (P.flags & 1u) != 0;
     const bool cw = P.front_face_cw != 0;
@@ -563,8 +574,6 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     int sp = 0;
     uint32_t w_next = 0, w_end = 0;   // the wave's claimed chunk, wave-uniform
     bool drained = false;
-    unsigned long long m_fetch = 0;
-    int c_fetch = 0;
 
     auto start_trace = [&]() {        // rayQueryInitialize, main.wgsl:80
         auto nz = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x; };
@@ -579,8 +588,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     // wave-uniform choice of the next phase body: the one most lanes wait for,
     // weighted (P.tune) so cheap bodies run at lower occupancy than expensive ones
     auto schedule = [&]() -> int {
-        m_fetch = __ballot(phase == PH_FETCH);
-        c_fetch = __popcll(m_fetch);
+        const int c_fetch = __popcll(__ballot(phase == PH_FETCH));
         const int c_node = __popcll(__ballot(phase == PH_NODE));
         const int c_leaf = __popcll(__ballot(phase == PH_LEAF));
         const int c_shade = __popcll(__ballot(phase == PH_SHADE));
@@ -687,22 +695,26 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 tl.pixel_frames++;
                 have_pixel = false;
             }
+            const unsigned long long m_free = __ballot(phase == PH_FETCH);
+            const int c_free = __popcll(m_free);
             if (w_next == w_end && !drained) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&P.queue->head, kChunk);
+                if (lane == 0) base = atomicAdd(&P.queue->head, P.chunk);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 if (base >= total_slots) { drained = true; }
-                else { w_next = base; w_end = min(base + kChunk, total_slots); }
+                else { w_next = base; w_end = min(base + P.chunk, total_slots); }
             }
             if (drained) {
                 if (phase == PH_FETCH) phase = PH_DONE;
             } else {
-                const uint32_t take = min(w_end - w_next, (uint32_t)c_fetch);
-                const uint32_t rank = (uint32_t)__popcll(m_fetch & ((1ull << lane) - 1ull));
+                const uint32_t take = min(w_end - w_next, (uint32_t)c_free);
+                const uint32_t rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
                 if (phase == PH_FETCH && rank < take) {
+                    uint32_t q = w_next + rank, f = 0;
+                    if (P.n_frames > 1u) { f = q / frame_slots; q -= f * frame_slots; }
                     uint32_t x, y, lr;
-                    if (slot_to_pixel(P, w_next + rank, x, y, lr)) {
-                        begin_pixel(P, C, S, x, y, lr);
+                    if (slot_to_pixel(P, q, x, y, lr)) {
+                        begin_pixel(P, C, S, x, y, lr, f);
                         have_pixel = true;
                         if (P.samples == 0) { S.total = v3(0.0f, 0.0f, 0.0f); }   // stays in FETCH: written out next round
                         else if (P.tune[5]) { phase = PH_NEXT; }
@@ -715,6 +727,22 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
         }
     }
     flush_tally<COUNT>(P, tl);
+}
+
+// Second half of a multi-frame launch: out = mix(old, mapped_f, 1 / (accumulation_frame + f + 1)) for
+// f = 0 .. n_frames-1 in order (main.wgsl:30-32), one thread per pixel, coalesced.
+__global__ __launch_bounds__(256) void rt_blend_frames(const RenderParams P, size_t n_pixels) {
+    const size_t pix = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (pix >= n_pixels) return;
+    float4 *dst = reinterpret_cast<float4 *>(P.accum) + pix;
+    const float4 old = *dst;
+    rt_v3 acc = v3(old.x, old.y, old.z);
+    for (uint32_t f = 0; f < P.n_frames; f++) {
+        const float4 m = P.stage[(size_t)f * P.stage_stride + pix];
+        const float w = 1.0f / (float)(P.accumulation_frame + f + 1u);
+        acc = rt_mix(acc, v3(m.x, m.y, m.z), w);
+    }
+    *dst = make_float4(acc.x, acc.y, acc.z, old.w);
 }
 
 // ---- variant 1: one wave per 8x8 tile (the reference's mapping) ----
@@ -780,20 +808,25 @@ hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool
     const size_t lds = (size_t)P.stack_entries * kBlock * sizeof(uint32_t);
     dim3 tile_grid((tiles + (kBlock / 64) - 1) / (kBlock / 64));
     // persistent grids: no more waves than chunks of work
-    uint32_t chunks = (tiles * 64u + kChunk - 1) / kChunk;
+    uint32_t chunks = (tiles * 64u + P.chunk - 1) / P.chunk;
     uint32_t blocks = (uint32_t)persistent_blocks;
     if (blocks > (chunks + 3) / 4) blocks = (chunks + 3) / 4;
     if (blocks == 0) blocks = 1;
     dim3 pgrid(blocks);
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
+    hipError_t e = hipSuccess;
     switch (sel) {
-        case 0: return launch_variant<false, false, false>(P, variant, tile_grid, pgrid, lds, stream);
-        case 1: return launch_variant<false, false, true>(P, variant, tile_grid, pgrid, lds, stream);
-        case 2: return launch_variant<false, true, false>(P, variant, tile_grid, pgrid, lds, stream);
-        case 3: return launch_variant<false, true, true>(P, variant, tile_grid, pgrid, lds, stream);
-        case 4: return launch_variant<true, false, false>(P, variant, tile_grid, pgrid, lds, stream);
-        case 5: return launch_variant<true, false, true>(P, variant, tile_grid, pgrid, lds, stream);
-        case 6: return launch_variant<true, true, false>(P, variant, tile_grid, pgrid, lds, stream);
-        default: return launch_variant<true, true, true>(P, variant, tile_grid, pgrid, lds, stream);
+        case 0: e = launch_variant<false, false, false>(P, variant, tile_grid, pgrid, lds, stream); break;
+        case 1: e = launch_variant<false, false, true>(P, variant, tile_grid, pgrid, lds, stream); break;
+        case 2: e = launch_variant<false, true, false>(P, variant, tile_grid, pgrid, lds, stream); break;
+        case 3: e = launch_variant<false, true, true>(P, variant, tile_grid, pgrid, lds, stream); break;
+        case 4: e = launch_variant<true, false, false>(P, variant, tile_grid, pgrid, lds, stream); break;
+        case 5: e = launch_variant<true, false, true>(P, variant, tile_grid, pgrid, lds, stream); break;
+        case 6: e = launch_variant<true, true, false>(P, variant, tile_grid, pgrid, lds, stream); break;
+        default: e = launch_variant<true, true, true>(P, variant, tile_grid, pgrid, lds, stream); break;
     }
+    if (e != hipSuccess || P.n_frames <= 1u) return e;
+    const size_t n_pixels = (size_t)P.local_rows * P.width;
+    if (n_pixels) rt_blend_frames<<<dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream>>>(P, n_pixels);
+    return hipGetLastError();
 }

@@ -465,3 +465,35 @@ def test_app_render_matches_oracle_frames(rt, oracle_mod, oracle_scenes):
         ou["frame"], ou["accumulation_frame"] = frame, af
         oracle_scenes("cornell-box").render(ou, acc, mode=1)
     assert_images_identical(got, acc, "app frames")
+
+
+@pytest.mark.parametrize("world,w,h,spp,frames", [(1, 96, 54, 2, 7), (3, 61, 37, 1, 5), (1, 40, 24, 0, 3)])
+def test_multi_frame_launch_equals_frame_by_frame(rt, oracle_mod, oracle_scenes, world, w, h, spp, frames):
+    """rt_dispatch_frames renders its frames in ONE launch (frame-major queue + per-pixel ordering flags,
+    RT_OPT_FRAME_PIPELINE).  Same bits as one launch per frame and as the oracle's frame loop (src/app.rs:78-96),
+    twice in a row (the flags of the first launch must not satisfy the second), also on a shard."""
+    cfg = config("C3")
+    rank = world - 1
+    def run(pipeline):
+        ctx = rt.Context(0)
+        ctx.set_option(rt.RT_OPT_FRAME_PIPELINE, pipeline)
+        ctx.scene_finish(rt.HostScene(scene_path("teapot-circle")))
+        ctx.set_shard(rank, world)
+        ctx.accum_resize(w, h)
+        u = uniforms_for(rt, cfg, w, h, samples=spp)
+        u["frame"], u["accumulation_frame"] = 0, 1
+        ctx.dispatch_frames(u, frames)
+        ctx.dispatch_frames(u, 2)
+        assert (int(u["frame"][0]), int(u["accumulation_frame"][0])) == (frames + 2, frames + 1)
+        st = ctx.stats()
+        img = ctx.accum_download()
+        ctx.close()
+        return img, st
+    a, st_a = run(1)
+    b, st_b = run(0)
+    assert st_a.rays == st_b.rays and st_a.pixel_frames == st_b.pixel_frames and st_a.dispatches == st_b.dispatches == frames + 2
+    assert_images_identical(a, b, "pipelined vs frame-by-frame")
+    if world == 1:
+        want, cnt = oracle_scenes("teapot-circle").render_frames(uniforms_for(oracle_mod, cfg, w, h, samples=spp), frames + 2, mode=1)
+        assert st_a.rays == cnt.rays
+        assert_images_identical(a, want, "pipelined vs oracle")
