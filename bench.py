@@ -155,8 +155,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    kernel_ms = ctx.last_dispatch_ms() / args.steps        # HIP events on the launch stream, per launch
     stats = ctx.stats()
+    launches = max(int(stats.launches), 1)                 # rt_dispatch_frames folds the K frames into one launch (or a few)
+    kernel_ms = ctx.last_dispatch_ms() / launches          # HIP events on the launch stream, per launch
     t = torch.tensor([dt], dtype=torch.float64, device=cdev)
     r = torch.tensor([stats.rays, stats.pixel_frames], dtype=torch.int64, device=cdev)
     k = torch.tensor([kernel_ms], dtype=torch.float64, device=cdev)
@@ -189,18 +190,20 @@ def main():
             out["cpu_baseline"] = {"value": cpu["mrays"], "unit": "Mrays/s", "cores": cpu["threads"], "kind": "port",
                                    "sample": f"oracle/rt_oracle.c (CPU restatement, not lavapipe), BVH mode, OpenMP; one {sw}x{sh} frame of the "
                                              f"same scene/camera, {cfg['samples']} spp, {cfg['max_bounces']} bounces: {cpu['rays']} rays in {cpu['seconds']:.2f} s"}
-            rays_per_launch = rays / args.steps / world       # per GPU, per launch
-            algo_bytes = rays_per_launch * cpu["bytes_per_ray"] + (W * H / world) * S_FB
+            rays_per_launch = rays / launches / world         # per GPU, per launch
+            algo_bytes = rays_per_launch * cpu["bytes_per_ray"] + (W * H / world) * (args.steps / launches) * S_FB
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
             # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE x2 on gfx950 +
             # WRITE_SIZE, MI355X_MICROARCH.md §HBM), recorded by tools/pmc_summary.py; null if never profiled
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and world == 1:
-                traffic = json.load(open(tpath)).get(args.config, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath)).get(args.config, {})
+                per_frame = rec.get("hbm_bytes_per_frame", rec.get("hbm_bytes_per_launch"))
+                traffic = None if per_frame is None else per_frame * args.steps / launches
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
-                               "kernel": "rt_render_phased", "kernel_ms": kernel_ms,
+                               "kernel": "rt_render_phased", "kernel_ms": kernel_ms, "frames_per_launch": args.steps / launches,
                                "bytes_per_ray": cpu["bytes_per_ray"], "nodes_per_ray": cpu["n_node"],
                                "tris_per_ray": cpu["n_tri"], "hit_fraction": cpu["hit"]}
         print(json.dumps(out), flush=True)
@@ -216,6 +219,7 @@ def main():
                 ref.spheres_upload(syn.spheres)
         else:
             ref.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
+        ref.set_option(rt.RT_OPT_FRAME_PIPELINE, 0)      # one launch per frame, blended in place
         ref.accum_resize(W, H)
         ref.dispatch_frames(fresh_uniform(), args.steps)
         want = ref.accum_download()

@@ -159,12 +159,13 @@ typedef struct RtStats {
     uint64_t wave_node_iters; /* idem: node-loop iterations summed over wavefronts (x64 = lane slots) */
     uint64_t wave_leaf_iters; /* idem: triangle-loop iterations summed over wavefronts */
     uint64_t wave_steps;      /* idem: (trace, shade) steps summed over wavefronts */
-    uint64_t dispatches;
+    uint64_t dispatches;      /* compute passes (frames) rendered */
     uint64_t bvh_nodes;       /* static: nodes in the device BVH */
     uint64_t bvh_bytes;       /* static: bytes of nodes + triangle records on device */
     double   bvh_build_seconds; /* last build or refit */
     uint64_t bvh_refits;      /* rt_models_update calls served by a refit */
     uint64_t bvh_rebuilds;    /* full builds (scene/sphere uploads, refit disabled) */
+    uint64_t launches;        /* render-kernel launches: rt_dispatch_frames folds a run of frames into one */
 } RtStats;
 
 /* rt_set_option keys */

@@ -95,7 +95,7 @@ struct rt_context {
     DevCounters *d_counters = nullptr;
     DevQueue *d_queue = nullptr;
     int persistent_blocks = 0;
-    uint64_t dispatches = 0;
+    uint64_t dispatches = 0, launches = 0;
 
     bool opt_count = false, opt_aov = false, opt_cw = false, opt_refit = true;
     int opt_node_stride = 0;
@@ -452,6 +452,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
     }
     RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->spheres.empty() || ctx->n_textures > 0, ctx->persistent_blocks, ctx->stream));
     ctx->dispatches += n_frames;
+    ctx->launches++;
     return RT_OK;
 }
 
@@ -749,6 +750,7 @@ int rt_stats(rt_context *ctx, RtStats *out) {
     out->bvh_build_seconds = ctx->build_seconds;
     out->bvh_refits = ctx->refits;
     out->bvh_rebuilds = ctx->rebuilds;
+    out->launches = ctx->launches;
     return RT_OK;
 }
 
@@ -756,7 +758,7 @@ int rt_stats_reset(rt_context *ctx) {
     if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipMemsetAsync(ctx->d_counters, 0, sizeof(DevCounters), ctx->stream));
-    ctx->dispatches = 0;
+    ctx->dispatches = 0; ctx->launches = 0;
     return RT_OK;
 }
 

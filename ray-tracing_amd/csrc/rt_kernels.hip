@@ -121,9 +121,12 @@ __device__ __forceinline__ void intersect_leaf(const DevTri *__restrict__ tris, 
 //   t    = off * inv + base            (one v_fma_mix_f32 per plane)
 // inv comes from v_rcp_f32 (1 ulp); a zero direction component is nudged to 1e-30
 // so no inf/NaN appears.  Error of t: relative 2^-22 |t| from inv and the last
-// rounding (covered by the 1.000001 factor), absolute <= 2^-24 (2|o| + |lo|) |inv|
+// rounding (covered by the kFarSlack factor), absolute <= 2^-24 (2|o| + |lo|) |inv|
 // from o*inv and base, covered by eps = 2^-21 max_k (|o_k| + R_k) |inv_k| with
 // R_k = max |coordinate| of the root box (RenderParams::scene_abs).
+// far bound factor of the box test: covers the relative error of t (rcp 2^-23, the phased kernel's stuffed
+// inverse 2^-18, two roundings 2^-23) on both sides of the comparison
+constexpr float kFarSlack = 1.000012f;
 typedef _Float16 rt_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float lo16(uint32_t w) { return (float)__builtin_bit_cast(rt_h2, w).x; }
 __device__ __forceinline__ float hi16(uint32_t w) { return (float)__builtin_bit_cast(rt_h2, w).y; }
@@ -159,8 +162,8 @@ __device__ __forceinline__ void test_node(const float4 *n, const Slab &sl, float
     const float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tbest));
     n1 = fmaxf(fmaxf(fminf(s0x, s1x), fminf(s0y, s1y)), fmaxf(fminf(s0z, s1z), kTMin));
     const float f1 = fminf(fminf(fmaxf(s0x, s1x), fmaxf(s0y, s1y)), fminf(fmaxf(s0z, s1z), tbest));
-    h0 = n0 <= fmaf(f0, 1.000001f, sl.eps);
-    h1 = n1 <= fmaf(f1, 1.000001f, sl.eps);
+    h0 = n0 <= fmaf(f0, kFarSlack, sl.eps);
+    h1 = n1 <= fmaf(f1, kFarSlack, sl.eps);
 }
 
 // nearest committed hit in (kTMin, kTMax): the ray query of main.wgsl:79-83
@@ -570,19 +573,22 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     int phase = PH_FETCH;
     bool have_pixel = false;  // FETCH: a finished pixel-frame waits to be written out
     int32_t cur = 0;          // NODE: inner node reference (float4 index); LEAF: leaf reference (< 0)
-    uint32_t leaf_pos = 0;    // LEAF: triangles of the leaf already tested
-    int sp = 0;
+    uint32_t *sptr = stack;   // next free entry of the lane's LDS stack (entries are kBlock words apart)
     uint32_t w_next = 0, w_end = 0;   // the wave's claimed chunk, wave-uniform
     bool drained = false;
 
     auto start_trace = [&]() {        // rayQueryInitialize, main.wgsl:80
         auto nz = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x; };
-        ix = __builtin_amdgcn_rcpf(nz(S.dir.x)); iy = __builtin_amdgcn_rcpf(nz(S.dir.y)); iz = __builtin_amdgcn_rcpf(nz(S.dir.z));
+        // the inverse direction carries, in mantissa bits 4:0, the rotate amount of the node step: 16 for a
+        // negative component (enter through the upper plane), else 0.  Costs 2^-18 of relative accuracy,
+        // which kFarSlack pays for.
+        auto stuff = [](float inv) { const uint32_t u = __float_as_uint(inv); return __uint_as_float((u & 0xFFFFFFE0u) | ((u >> 27) & 16u)); };
+        ix = stuff(__builtin_amdgcn_rcpf(nz(S.dir.x))); iy = stuff(__builtin_amdgcn_rcpf(nz(S.dir.y))); iz = stuff(__builtin_amdgcn_rcpf(nz(S.dir.z)));
         ox = -(S.pos.x * ix); oy = -(S.pos.y * iy); oz = -(S.pos.z * iz);
         eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(ox)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(oy))),
                                      fmaf(P.scene_abs[2], fabsf(iz), fabsf(oz)));   // see make_slab
         best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
-        cur = 0; sp = 0; leaf_pos = 0;
+        cur = 0; sptr = stack;
         phase = PH_NODE;
     };
     // wave-uniform choice of the next phase body: the one most lanes wait for,
@@ -615,50 +621,51 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                     const uint4 b = ld4u(n + 1), c = ld4u(n + 2);
                     const int2 refs = make_int2(__float_as_int(a.w), (int32_t)b.w);
                     const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
-                    float t0x = fmaf(lo16(b.x), ix, bx), t1x = fmaf(hi16(b.x), ix, bx);
-                    float t0y = fmaf(lo16(b.y), iy, by), t1y = fmaf(hi16(b.y), iy, by);
-                    float t0z = fmaf(lo16(b.z), iz, bz), t1z = fmaf(hi16(b.z), iz, bz);
-                    float s0x = fmaf(lo16(c.x), ix, bx), s1x = fmaf(hi16(c.x), ix, bx);
-                    float s0y = fmaf(lo16(c.y), iy, by), s1y = fmaf(hi16(c.y), iy, by);
-                    float s0z = fmaf(lo16(c.z), iz, bz), s1z = fmaf(hi16(c.z), iz, bz);
-                    float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
-                    float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), best.t));
-                    float n1 = fmaxf(fmaxf(fminf(s0x, s1x), fminf(s0y, s1y)), fmaxf(fminf(s0z, s1z), kTMin));
-                    float f1 = fminf(fminf(fmaxf(s0x, s1x), fmaxf(s0y, s1y)), fminf(fmaxf(s0z, s1z), best.t));
-                    const bool h0 = n0 <= fmaf(f0, 1.000001f, eps);
-                    const bool h1 = n1 <= fmaf(f1, 1.000001f, eps);
+                    // rotate each (hi << 16 | lo) offset pair by 0 or 16 bits (bits 4:0 of the stuffed inverse,
+                    // see start_trace): the low half becomes the plane the ray ENTERS through, no min/max needed
+                    const uint32_t rx = __float_as_uint(ix), ry = __float_as_uint(iy), rz = __float_as_uint(iz);
+                    const uint32_t p0x = __builtin_amdgcn_alignbit(b.x, b.x, rx), p0y = __builtin_amdgcn_alignbit(b.y, b.y, ry),
+                                   p0z = __builtin_amdgcn_alignbit(b.z, b.z, rz);
+                    const uint32_t p1x = __builtin_amdgcn_alignbit(c.x, c.x, rx), p1y = __builtin_amdgcn_alignbit(c.y, c.y, ry),
+                                   p1z = __builtin_amdgcn_alignbit(c.z, c.z, rz);
+                    const float n0 = fmaxf(fmaxf(fmaf(lo16(p0x), ix, bx), fmaf(lo16(p0y), iy, by)), fmaxf(fmaf(lo16(p0z), iz, bz), kTMin));
+                    const float f0 = fminf(fminf(fmaf(hi16(p0x), ix, bx), fmaf(hi16(p0y), iy, by)), fminf(fmaf(hi16(p0z), iz, bz), best.t));
+                    const float n1 = fmaxf(fmaxf(fmaf(lo16(p1x), ix, bx), fmaf(lo16(p1y), iy, by)), fmaxf(fmaf(lo16(p1z), iz, bz), kTMin));
+                    const float f1 = fminf(fminf(fmaf(hi16(p1x), ix, bx), fmaf(hi16(p1y), iy, by)), fminf(fmaf(hi16(p1z), iz, bz), best.t));
+                    const bool h0 = n0 <= fmaf(f0, kFarSlack, eps);
+                    const bool h1 = n1 <= fmaf(f1, kFarSlack, eps);
                     // next reference: the nearer hit child; the other one (if hit) is pushed
                     const bool take1 = h1 && (!h0 || n1 < n0);
                     int32_t nxt = take1 ? refs.y : refs.x;
-                    if (h0 && h1) { stack[sp * kBlock] = (uint32_t)(take1 ? refs.x : refs.y); sp++; }
-                    phase = PH_NODE;
-                    if (!h0 && !h1) {
-                        if (sp == 0) { phase = PH_SHADE; nxt = 0; }
-                        else { sp--; nxt = (int32_t)stack[sp * kBlock]; }
+                    if (h0 && h1) { *sptr = (uint32_t)(take1 ? refs.x : refs.y); sptr += kBlock; }
+                    bool finished = false;
+                    if (!(h0 || h1)) {
+                        if (sptr == stack) { finished = true; }
+                        else { sptr -= kBlock; nxt = (int32_t)*sptr; }
                     }
                     cur = nxt;
-                    leaf_pos = 0;
-                    if (nxt < 0) phase = PH_LEAF;
+                    phase = (int)((uint32_t)nxt >> 31);          // PH_NODE (ref >= 0) or PH_LEAF (ref < 0)
+                    if (finished) phase = PH_SHADE;
                 }
                 pick = schedule();
             } while (pick == PH_NODE);
         } else if (pick == PH_LEAF) {
             do {
                 if (phase == PH_LEAF) {
-                    const uint32_t enc = (uint32_t)~cur;
-                    const uint32_t n_in_leaf = enc & 7u;
-                    if (leaf_pos < n_in_leaf) {
+                    // ~cur = first_slot << 3 | triangles left: tested last to first, the count runs down in place
+                    uint32_t enc = (uint32_t)~cur;
+                    if (enc & 7u) {
                         if (COUNT) { tl.tris++; if (first_active_lane()) tl.w_leaf++; }
-                        intersect_tri<SPH>(P.tris, (enc >> 3) + leaf_pos, S.pos, S.dir, cull, cw, best);
+                        enc--;
+                        intersect_tri<SPH>(P.tris, (enc >> 3) + (enc & 7u), S.pos, S.dir, cull, cw, best);
                     }
-                    leaf_pos++;
-                    if (leaf_pos >= n_in_leaf) {
-                        if (sp == 0) { phase = PH_SHADE; }
+                    cur = (int32_t)~enc;
+                    if ((enc & 7u) == 0u) {
+                        if (sptr == stack) { phase = PH_SHADE; }
                         else {
-                            sp--;
-                            cur = (int32_t)stack[sp * kBlock];
-                            leaf_pos = 0;
-                            phase = cur >= 0 ? PH_NODE : PH_LEAF;
+                            sptr -= kBlock;
+                            cur = (int32_t)*sptr;
+                            phase = (int)((uint32_t)cur >> 31);
                         }
                     }
                 }
@@ -699,10 +706,18 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
             const int c_free = __popcll(m_free);
             if (w_next == w_end && !drained) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&P.queue->head, P.chunk);
+                // guided grain: 4 chunks per claim while plenty of work is left (coherent tiles), one chunk near
+                // the end so that the last claims do not turn into a long tail
+                uint32_t grain = P.chunk;
+                if (lane == 0) {
+                    const uint32_t seen = __hip_atomic_load(&P.queue->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen < total_slots && total_slots - seen > gridDim.x * (kBlock / 64u) * P.chunk * 8u) grain = P.chunk * 4u;
+                    base = atomicAdd(&P.queue->head, grain);
+                }
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                grain = (uint32_t)__builtin_amdgcn_readfirstlane((int)grain);
                 if (base >= total_slots) { drained = true; }
-                else { w_next = base; w_end = min(base + P.chunk, total_slots); }
+                else { w_next = base; w_end = min(base + grain, total_slots); }
             }
             if (drained) {
                 if (phase == PH_FETCH) phase = PH_DONE;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise a profiles/run_profile.sh output directory: kernel stats + per-launch PMC means + derived figures.
-usage: python tools/pmc_summary.py gpurun_out/prof_<tag> [out_dir [config-key-for-profiles/traffic.json]]"""
+usage: python tools/pmc_summary.py gpurun_out/prof_<tag> [out_dir [config-key-for-profiles/traffic.json [frames-per-launch]]]
+The profiled command (profiles/run_profile.sh) makes every rt_render launch the same size: --steps S --warmup S."""
 import collections, csv, glob, json, os, shutil, sys
 src = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else None
@@ -37,7 +38,10 @@ if out and len(sys.argv) > 3:
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tp = os.path.join(root, "profiles", "traffic.json")
     t = json.load(open(tp)) if os.path.exists(tp) else {}
+    fpl = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     t[sys.argv[3]] = {"hbm_bytes_per_launch": d["derived"]["hbm_read_bytes_x2"] + d["derived"]["hbm_write_bytes"],
+                      "frames_per_launch": fpl,
+                      "hbm_bytes_per_frame": (d["derived"]["hbm_read_bytes_x2"] + d["derived"]["hbm_write_bytes"]) / fpl,
                       "read_bytes_fetch_size_x2": d["derived"]["hbm_read_bytes_x2"], "write_bytes": d["derived"]["hbm_write_bytes"],
                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE KiB x 2 (gfx950 reads half), WRITE_SIZE KiB x 1",
                       "profile": out}
