@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+# RT_AMD_LIB: developer override to A/B another build of the same library (tools/)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")
 
 # ---------------------------------------------------------------- layouts
 # numpy views of the structs in include/rt_abi.h (offsets asserted there)
