@@ -180,6 +180,7 @@ def main():
             "config": {"workload": f"{args.config}: {os.path.basename(cfg['scene'])} {W}x{H}, {cfg['samples']} spp/step x {args.steps} steps, "
                                    f"{cfg['max_bounces']} bounces, 8-row bands round-robin over {world} GPU(s), one framebuffer gather",
                        "bvh_nodes": int(stats.bvh_nodes), "bvh_gbytes": stats.bvh_bytes / 1e9, "bvh_build_s": stats.bvh_build_seconds,
+                       "stack_entries": int(stats.stack_entries), "resident_waves_per_simd": int(stats.resident_blocks) * 4 / 1024,
                        "rays": rays, "spp": cfg["samples"] * args.steps,
                        "spp_per_s": cfg["samples"] * args.steps / dt, "msamples_per_s": W * H * cfg["samples"] * args.steps / dt / 1e6},
         }

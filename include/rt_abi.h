@@ -166,6 +166,8 @@ typedef struct RtStats {
     uint64_t bvh_refits;      /* rt_models_update calls served by a refit */
     uint64_t bvh_rebuilds;    /* full builds (scene/sphere uploads, refit disabled) */
     uint64_t launches;        /* render-kernel launches: rt_dispatch_frames folds a run of frames into one */
+    uint32_t stack_entries;   /* static: traversal stack entries per lane (BVH depth + 1), 1 KiB of LDS each per workgroup */
+    uint32_t resident_blocks; /* workgroups of 256 the persistent kernel keeps resident (0 before the first launch) */
 } RtStats;
 
 /* rt_set_option keys */
@@ -245,7 +247,13 @@ int rt_dispatch(rt_context *ctx, const RtUniform *uniform);
 /* n_frames consecutive dispatches; before each one `frame` is bumped and
  * `accumulation_frame` follows the cold-start sequence of src/app.rs:78-96
  * (first dispatch after a resize sees accumulation_frame = 0).  On return
- * *uniform holds the values of the last dispatch. */
+ * *uniform holds the values of the last dispatch.  With the default kernel the
+ * run is rendered by ONE launch (RT_OPT_FRAME_PIPELINE): pixel-frames are worked
+ * off frame-major, their colours parked per frame (device staging, allocated on
+ * first use, <= 4 GiB) and blended into the accumulation buffer in frame order —
+ * the same bits as n_frames separate rt_dispatch calls.  Falls back to one launch
+ * per frame when RT_OPT_AOV is set, for the other kernel variants and for
+ * windows 65536 pixels wide or wider. */
 int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames);
 int rt_sync(rt_context *ctx);
 

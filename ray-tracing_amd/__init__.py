@@ -112,7 +112,8 @@ class RtStats(C.Structure):
                 ("triangle_tests", C.c_uint64), ("wave_node_iters", C.c_uint64), ("wave_leaf_iters", C.c_uint64),
                 ("wave_steps", C.c_uint64), ("dispatches", C.c_uint64), ("bvh_nodes", C.c_uint64),
                 ("bvh_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double), ("bvh_refits", C.c_uint64),
-                ("bvh_rebuilds", C.c_uint64), ("launches", C.c_uint64)]
+                ("bvh_rebuilds", C.c_uint64), ("launches", C.c_uint64),
+                ("stack_entries", C.c_uint32), ("resident_blocks", C.c_uint32)]
 
 
 class RtBvhInfo(C.Structure):

@@ -267,7 +267,8 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         if (!c1.count) todo.push_back({n.left + 1, d1});
         if (!c0.count) todo.push_back({n.left, d0});
     }
-    out.stack_entries = bvh.max_depth + 2;
+    // a depth-first walk pushes at most one reference per inner node on the path: max_depth entries (+1 spare)
+    out.stack_entries = bvh.max_depth + 1;
 }
 
 int build_and_upload(rt_context *ctx, bool allow_refit = false) {
@@ -751,6 +752,8 @@ int rt_stats(rt_context *ctx, RtStats *out) {
     out->bvh_refits = ctx->refits;
     out->bvh_rebuilds = ctx->rebuilds;
     out->launches = ctx->launches;
+    out->stack_entries = ctx->stack_entries;
+    out->resident_blocks = (uint32_t)ctx->persistent_blocks;
     return RT_OK;
 }
 
