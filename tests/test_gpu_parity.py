@@ -497,3 +497,86 @@ def test_multi_frame_launch_equals_frame_by_frame(rt, oracle_mod, oracle_scenes,
         want, cnt = oracle_scenes("teapot-circle").render_frames(uniforms_for(oracle_mod, cfg, w, h, samples=spp), frames + 2, mode=1)
         assert st_a.rays == cnt.rays
         assert_images_identical(a, want, "pipelined vs oracle")
+
+
+def _soup(obj_loader, rng, n, centre, spread, size):
+    """n random triangles around `centre`: corners within `size` of a point drawn within `spread`."""
+    c = centre + (rng.random((n, 1, 3)) - 0.5) * 2 * spread
+    p = (c + (rng.random((n, 3, 3)) - 0.5) * 2 * size).astype(np.float32)
+    v = np.zeros(3 * n, obj_loader.VERTEX_DTYPE)
+    v["position"] = p.reshape(-1, 3)
+    nrm = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-20)
+    v["normal"] = np.repeat(nrm.astype(np.float32), 3, axis=0)
+    pr = np.zeros(1, obj_loader.PRIMITIVE_DTYPE)
+    pr[0] = (0, 3 * n, 0, 3 * n, 0)
+    md = np.zeros(1, obj_loader.MODEL_DTYPE)
+    md["diffuse_color"] = (0.7, 0.6, 0.5)
+    md["specular_color"] = (0.9, 0.9, 0.9)
+    md["specular_probability"] = 0.3
+    return obj_loader.Scene(v, np.arange(3 * n, dtype=np.uint32), pr, md)
+
+
+@pytest.mark.parametrize("case", ["far_from_origin", "huge_extent_ratio", "axis_parallel_rays", "flat_sheet"])
+def test_box_test_stays_conservative(rt, oracle_mod, obj_loader, case):
+    """The ray/box test is the one part outside the arithmetic contract (f16 child offsets, v_rcp, 5 stuffed
+    mantissa bits): it must never cull a hit that BRUTE FORCE finds.  Scenes built to strain it: small triangles
+    10^4 units from the origin (cancellation in plane*inv - o*inv), a 10^6:1 extent ratio (offsets at the bottom
+    of the f16 range next to offsets at the top), a camera looking exactly along an axis through an axis-aligned
+    grid (direction components of exactly 0), all triangles in one plane (zero-thickness boxes)."""
+    rng = np.random.default_rng(11)
+    w, h, spp, bounces = 64, 40, 2, 4
+    pos, yaw, pitch = (0.0, 0.0, -6.0), np.pi / 2, 0.0          # yaw pi/2 looks along +z (ray.wgsl:52-58)
+    if case == "far_from_origin":
+        centre = np.array([10000.0, -7000.0, 12000.0])
+        s = _soup(obj_loader, rng, 3000, centre, 2.0, 0.25)
+        pos = tuple(centre + np.array([0.0, 0.0, -6.0]))
+    elif case == "huge_extent_ratio":
+        a = _soup(obj_loader, rng, 2500, np.zeros(3), 1.5, 0.15)
+        b = _soup(obj_loader, rng, 40, np.zeros(3), 2.0e4, 3.0e3)
+        v = np.zeros(len(a.vertices) + len(b.vertices), obj_loader.VERTEX_DTYPE)   # (concatenate would drop the padding)
+        v[:len(a.vertices)] = a.vertices
+        v[len(a.vertices):] = b.vertices
+        pr = a.primitives.copy()
+        pr[0] = (0, len(v), 0, len(v), 0)
+        s = obj_loader.Scene(v, np.arange(len(v), dtype=np.uint32), pr, a.models)
+    elif case == "axis_parallel_rays":
+        # unit quads on the integer grid in the planes z = 0..3, camera on a grid line, fov tiny: primary rays run
+        # (almost) exactly along +z, many with dx = dy = 0 after the jitter-free centre pixel
+        quads = []
+        for z in range(4):
+            for x in range(-3, 3):
+                for y in range(-3, 3):
+                    if (x + y + z) % 2 == 0:
+                        quads.append([[x, y, z], [x + 1, y, z], [x + 1, y + 1, z], [x, y, z], [x + 1, y + 1, z], [x, y + 1, z]])
+        p = np.array(quads, np.float32).reshape(-1, 3)
+        v = np.zeros(len(p), obj_loader.VERTEX_DTYPE)
+        v["position"] = p
+        v["normal"] = (0, 0, -1)
+        pr = np.zeros(1, obj_loader.PRIMITIVE_DTYPE)
+        pr[0] = (0, len(p), 0, len(p), 0)
+        md = np.zeros(1, obj_loader.MODEL_DTYPE)
+        md["diffuse_color"] = (0.8, 0.8, 0.8)
+        md["specular_probability"] = 1.0          # mirror: reflected rays stay axis-parallel
+        md["specular_color"] = (1, 1, 1)
+        s = obj_loader.Scene(v, np.arange(len(p), dtype=np.uint32), pr, md)
+    else:
+        s = _soup(obj_loader, rng, 600, np.zeros(3), 2.0, 0.3)
+        s.vertices["position"][:, 2] = 1.25       # everything in the plane z = 1.25
+        s.vertices["normal"] = (0, 0, -1)
+    kw = dict(max_bounces=bounces, samples=spp)
+    if case == "axis_parallel_rays":
+        kw["fov"] = 1e-4
+    want, want_hits, cnt = oracle_mod.OracleScene(s, build_bvh=False).render(
+        oracle_mod.make_uniform(w, h, pos, yaw, pitch, **kw), mode=0, want_hits=True)
+    assert (want_hits[..., 0] != 0xFFFFFFFF).mean() > 0.05, "the camera must see the scene for the test to mean anything"
+    for stride in (3, 4):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.RT_OPT_NODE_STRIDE, stride)
+            ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+            ctx.set_option(rt.RT_OPT_AOV, 1)
+            ctx.accum_resize(w, h)
+            ctx.dispatch(rt.make_uniform(w, h, pos, yaw, pitch, **kw))
+            assert ctx.stats().rays == cnt.rays
+            assert np.array_equal(ctx.aov_download(), want_hits), f"{case}: primary hit ids differ from brute force"
+            assert_images_identical(ctx.accum_download(), want, f"{case} stride {stride}")
