@@ -104,6 +104,7 @@ struct rt_context {
     float4 *d_stage = nullptr;       // per-frame tone-mapped colours of a multi-frame launch (lazy, grows)
     uint64_t stage_elems = 0;
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
+    uint64_t stage_budget = 4ull << 30;   // bytes of staging a multi-frame launch may use (key 109, tests)
     uint32_t chunk = 64;             // queue grain: small enough that the last chunk is not a long tail
     bool timed = false;
 };
@@ -541,6 +542,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
         default:
             if (key >= 100 && key < 108) { ctx->tune[key - 100] = (int32_t)value; return RT_OK; }
             if (key == 108 && value >= 1 && value <= 65536) { ctx->chunk = (uint32_t)value; return RT_OK; }
+            if (key == 109 && value >= 1) { ctx->stage_budget = (uint64_t)value << 10; return RT_OK; }   // KiB
             return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);
     }
 }
@@ -679,7 +681,7 @@ int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames) {
     uint32_t group_max = 1;
     if (ctx->opt_pipeline && ctx->opt_kernel == 2 && !ctx->opt_aov && ctx->width < 65536u && frame_slots > 0) {
         const uint64_t by_queue = 0xFFFFFFFFull / frame_slots;                       // 32-bit work-queue index
-        const uint64_t by_stage = (4ull << 30) / (frame_slots * sizeof(float4));      // <= 4 GiB of staging
+        const uint64_t by_stage = ctx->stage_budget / (frame_slots * sizeof(float4));   // <= 4 GiB of staging
         const uint64_t cap = by_queue < by_stage ? by_queue : by_stage;
         group_max = (uint32_t)(cap < 65535u ? cap : 65535u);
         if (group_max == 0) group_max = 1;

@@ -467,16 +467,19 @@ def test_app_render_matches_oracle_frames(rt, oracle_mod, oracle_scenes):
     assert_images_identical(got, acc, "app frames")
 
 
-@pytest.mark.parametrize("world,w,h,spp,frames", [(1, 96, 54, 2, 7), (3, 61, 37, 1, 5), (1, 40, 24, 0, 3)])
-def test_multi_frame_launch_equals_frame_by_frame(rt, oracle_mod, oracle_scenes, world, w, h, spp, frames):
+@pytest.mark.parametrize("world,w,h,spp,frames,stage_kib", [(1, 96, 54, 2, 7, 0), (3, 61, 37, 1, 5, 0), (1, 40, 24, 0, 3, 0),
+                                                             (1, 64, 40, 1, 9, 100)])
+def test_multi_frame_launch_equals_frame_by_frame(rt, oracle_mod, oracle_scenes, world, w, h, spp, frames, stage_kib):
     """rt_dispatch_frames renders its frames in ONE launch (frame-major queue + per-pixel ordering flags,
     RT_OPT_FRAME_PIPELINE).  Same bits as one launch per frame and as the oracle's frame loop (src/app.rs:78-96),
-    twice in a row (the flags of the first launch must not satisfy the second), also on a shard."""
+    twice in a row, also on a shard, and with a staging budget so small that the run splits into launches of two frames."""
     cfg = config("C3")
     rank = world - 1
     def run(pipeline):
         ctx = rt.Context(0)
         ctx.set_option(rt.RT_OPT_FRAME_PIPELINE, pipeline)
+        if stage_kib:
+            ctx.set_option(109, stage_kib)          # 64*40 pixels * 16 B = 40 KiB per frame -> 2 frames per launch
         ctx.scene_finish(rt.HostScene(scene_path("teapot-circle")))
         ctx.set_shard(rank, world)
         ctx.accum_resize(w, h)
@@ -492,6 +495,7 @@ def test_multi_frame_launch_equals_frame_by_frame(rt, oracle_mod, oracle_scenes,
     a, st_a = run(1)
     b, st_b = run(0)
     assert st_a.rays == st_b.rays and st_a.pixel_frames == st_b.pixel_frames and st_a.dispatches == st_b.dispatches == frames + 2
+    assert st_b.launches == frames + 2 and st_a.launches == (2 if not stage_kib else (frames + 1) // 2 + 1)
     assert_images_identical(a, b, "pipelined vs frame-by-frame")
     if world == 1:
         want, cnt = oracle_scenes("teapot-circle").render_frames(uniforms_for(oracle_mod, cfg, w, h, samples=spp), frames + 2, mode=1)
