@@ -21,6 +21,8 @@ cyc = vals.get('GRBM_GUI_ACTIVE', 0) / 8
 if cyc:
     d["derived"] = {
         "shader_clock_GHz": cyc / (avg_ms * 1e-3) / 1e9,
+        # rocprof's VALUBusy formula (4 cycles per wave64 VALU instruction, 1024 SIMDs).  An estimate: it reads
+        # slightly above 1 when the pipes are saturated, because not every VALU instruction holds a pipe 4 cycles.
         "valu_busy": vals['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / cyc,
         "valu_lane_utilization": vals['SQ_THREAD_CYCLES_VALU'] / (vals['SQ_ACTIVE_INST_VALU'] * 64),
         "waves_per_simd": vals['SQ_WAVE_CYCLES'] * 4 / 1024 / cyc,
