@@ -132,6 +132,7 @@ def main():
 
     # warm-up: W untimed steps (+ one gather so RCCL's channels exist)
     ctx.accum_bind(local.data_ptr(), local.numel() * 4, W, H)
+    ctx.frames_reserve(args.steps)       # staging of the K-frame launch: allocated here, not in the timed region
     u = fresh_uniform()
     if args.warmup > 0:
         ctx.dispatch_frames(u, args.warmup)

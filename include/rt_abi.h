@@ -255,6 +255,10 @@ int rt_dispatch(rt_context *ctx, const RtUniform *uniform);
  * per frame when RT_OPT_AOV is set, for the other kernel variants and for
  * windows 65536 pixels wide or wider. */
 int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames);
+/* Allocates the staging of rt_dispatch_frames for runs of up to n_frames frames now (after
+ * rt_accum_resize / rt_accum_bind), so that the dispatch itself does not allocate.  No
+ * counterpart in the reference (its accumulation is one dispatch per frame). */
+int rt_frames_reserve(rt_context *ctx, uint32_t n_frames);
 int rt_sync(rt_context *ctx);
 
 /* ---------------------------------------------------------------- readback */

@@ -395,23 +395,39 @@ int ensure_aov(rt_context *ctx) {
     return RT_OK;
 }
 
+// frames a multi-frame launch may take: 32-bit work-queue index, staging budget, 16-bit frame field of the pixel state
+uint32_t frame_group_max(const rt_context *ctx) {
+    const uint64_t frame_slots = (uint64_t)((ctx->width + 7u) / 8u) * ctx->local_bands * 64u;
+    if (!ctx->opt_pipeline || ctx->opt_kernel != 2 || ctx->opt_aov || ctx->width >= 65536u || frame_slots == 0) return 1;
+    const uint64_t by_queue = 0xFFFFFFFFull / frame_slots;
+    const uint64_t by_stage = ctx->stage_budget / (frame_slots * sizeof(float4));
+    const uint64_t cap = by_queue < by_stage ? by_queue : by_stage;
+    return cap < 1 ? 1u : (uint32_t)(cap < 65535u ? cap : 65535u);
+}
+
+// staging planes for launches of up to n_frames frames (grows, never shrinks)
+int ensure_stage(rt_context *ctx, uint32_t n_frames) {
+    const uint64_t stride = local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count) * ctx->width;
+    const uint64_t need = (stride ? stride : 1) * n_frames;
+    if (ctx->stage_elems >= need) return RT_OK;
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->d_stage);
+    ctx->stage_elems = 0;
+    RT_HIP(hipMalloc((void **)&ctx->d_stage, need * sizeof(float4)));
+    ctx->stage_elems = need;
+    return RT_OK;
+}
+
 int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
     RenderParams P;
     memset(&P, 0, sizeof P);
     P.n_frames = n_frames;
     P.local_rows = (uint32_t)local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count);
     if (n_frames > 1) {
-        const uint64_t stride = (uint64_t)P.local_rows * ctx->width;
-        const uint64_t need = (stride ? stride : 1) * n_frames;
-        if (ctx->stage_elems < need) {
-            RT_HIP(hipStreamSynchronize(ctx->stream));
-            dev_free(ctx->d_stage);
-            ctx->stage_elems = 0;
-            RT_HIP(hipMalloc((void **)&ctx->d_stage, need * sizeof(float4)));
-            ctx->stage_elems = need;
-        }
+        int r = ensure_stage(ctx, n_frames);
+        if (r) return r;
         P.stage = ctx->d_stage;
-        P.stage_stride = stride;
+        P.stage_stride = (uint64_t)P.local_rows * ctx->width;
     }
     P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
     P.textures = ctx->d_textures; P.texels = ctx->d_texels; P.n_textures = ctx->n_textures;
@@ -659,6 +675,14 @@ int rt_accum_bind(rt_context *ctx, void *device_ptr, uint64_t bytes, uint32_t w,
     return setup_accum(ctx, w, h);
 }
 
+int rt_frames_reserve(rt_context *ctx, uint32_t n_frames) {
+    if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
+    if (!ctx->d_accum) return fail(RT_ERR_NO_ACCUM, "rt_frames_reserve before rt_accum_resize/rt_accum_bind");
+    RT_HIP(hipSetDevice(ctx->device));
+    const uint32_t group = n_frames < frame_group_max(ctx) ? n_frames : frame_group_max(ctx);
+    return group > 1 ? ensure_stage(ctx, group) : RT_OK;
+}
+
 int rt_dispatch(rt_context *ctx, const RtUniform *uniform) {
     int r = check_dispatch(ctx, uniform);
     if (r) return r;
@@ -677,15 +701,7 @@ int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames) {
     RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     // The phased kernel takes a run of frames in ONE launch (frame-major work queue, per-pixel ordering flags):
     // the slow tail of a frame, where the last long pixels run on a nearly empty GPU, overlaps the next frame.
-    const uint64_t frame_slots = (uint64_t)((ctx->width + 7u) / 8u) * ctx->local_bands * 64u;
-    uint32_t group_max = 1;
-    if (ctx->opt_pipeline && ctx->opt_kernel == 2 && !ctx->opt_aov && ctx->width < 65536u && frame_slots > 0) {
-        const uint64_t by_queue = 0xFFFFFFFFull / frame_slots;                       // 32-bit work-queue index
-        const uint64_t by_stage = ctx->stage_budget / (frame_slots * sizeof(float4));   // <= 4 GiB of staging
-        const uint64_t cap = by_queue < by_stage ? by_queue : by_stage;
-        group_max = (uint32_t)(cap < 65535u ? cap : 65535u);
-        if (group_max == 0) group_max = 1;
-    }
+    const uint32_t group_max = frame_group_max(ctx);
     uint32_t i = 0;
     while (i < n_frames) {
         const uint32_t group = (n_frames - i < group_max) ? n_frames - i : group_max;
