@@ -15,16 +15,16 @@
 // Variant 2 (default) — persistent wavefronts, lanes scheduled by phase
 //   (rt_render_phased, see the comment above it).
 // Variant 0 — persistent wavefronts with a work queue, one whole ray per step:
-//   each wave claims chunks of 256 pixel slots from a global head with one
-//   atomic and hands slots to its lanes as they finish.
+//   each wave claims chunks of pixel slots from a global head with one atomic
+//   and hands slots to its lanes as they finish.
 // Variant 1 — one wave per 8x8 tile, one lane per pixel, the reference's own
 //   mapping (main.wgsl:15).
 // Variants 0 and 1 are kept for A/B measurements (RT_OPT_KERNEL).
 //
 // Arithmetic follows the RTN-1 contract (rt_math.h): results are bit-identical
 // to oracle/rt_oracle.c.  Only the ray/box test is free to differ (it must be
-// conservative, nothing more), so it uses v_rcp_f32, packed FMAs and a widened
-// far bound.
+// conservative, nothing more), so it uses v_rcp_f32, f16 box offsets fed to
+// v_fma_mix_f32 and a widened far bound (see Slab / the node step below).
 #include <hip/hip_runtime.h>
 
 #include "rt_device.h"
@@ -43,8 +43,6 @@ constexpr float kTMin = 0.001f;              // main.wgsl:77
 constexpr float kTMax = 3.40282347e+38f;     // main.wgsl:77
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-
 struct Hit {
     float t, u, v;
     uint32_t slot;   // leaf-order triangle slot, kNoHit = miss
@@ -57,7 +55,6 @@ struct Tally {      // per-lane counters; the wave-level ones only in counting b
 };
 
 __device__ __forceinline__ float4 ld4(const void *p) { return *reinterpret_cast<const float4 *>(p); }
-__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 __device__ __forceinline__ bool first_active_lane() {
     unsigned long long m = __ballot(1);
     return (threadIdx.x & 63u) == (unsigned)(__ffsll((long long)m) - 1);
