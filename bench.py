@@ -185,15 +185,21 @@ def main():
                        "rays": rays, "spp": cfg["samples"] * args.steps,
                        "spp_per_s": cfg["samples"] * args.steps / dt, "msamples_per_s": W * H * cfg["samples"] * args.steps / dt / 1e6},
         }
-        cpu = None
-        if not args.no_cpu:
+        # cpu_baseline: rank 0 at N=1 only.  The roofline's per-ray byte model comes from the same oracle run
+        # (counting mode); without that leg it is taken from configs/baseline_configs.json (same measurement, frozen).
+        model, model_src = cfg.get("byte_model"), "configs/baseline_configs.json"
+        if not args.no_cpu and world == 1:
             sw, sh = (int(x) for x in args.cpu_sample.split("x"))
             cpu = cpu_baseline_and_byte_model(cfg, sw, sh)
             out["cpu_baseline"] = {"value": cpu["mrays"], "unit": "Mrays/s", "cores": cpu["threads"], "kind": "port",
                                    "sample": f"oracle/rt_oracle.c (CPU restatement, not lavapipe), BVH mode, OpenMP; one {sw}x{sh} frame of the "
                                              f"same scene/camera, {cfg['samples']} spp, {cfg['max_bounces']} bounces: {cpu['rays']} rays in {cpu['seconds']:.2f} s"}
+            model = {"nodes_per_ray": cpu["n_node"], "tris_per_ray": cpu["n_tri"], "hit_fraction": cpu["hit"]}
+            model_src = "measured by this run's cpu_baseline leg"
+        if model is not None:
+            bytes_per_ray = model["nodes_per_ray"] * S_NODE + model["tris_per_ray"] * S_TRI + model["hit_fraction"] * S_HIT
             rays_per_launch = rays / launches / world         # per GPU, per launch
-            algo_bytes = rays_per_launch * cpu["bytes_per_ray"] + (W * H / world) * (args.steps / launches) * S_FB
+            algo_bytes = rays_per_launch * bytes_per_ray + (W * H / world) * (args.steps / launches) * S_FB
             achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
             # HBM bytes per launch from the rocprofv3 PMC passes of the same command (FETCH_SIZE x2 on gfx950 +
             # WRITE_SIZE, MI355X_MICROARCH.md §HBM), recorded by tools/pmc_summary.py; null if never profiled
@@ -206,8 +212,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": algo_bytes,
                                "kernel": "rt_render_phased", "kernel_ms": kernel_ms, "frames_per_launch": args.steps / launches,
-                               "bytes_per_ray": cpu["bytes_per_ray"], "nodes_per_ray": cpu["n_node"],
-                               "tris_per_ray": cpu["n_tri"], "hit_fraction": cpu["hit"]}
+                               "bytes_per_ray": bytes_per_ray, "nodes_per_ray": model["nodes_per_ray"],
+                               "tris_per_ray": model["tris_per_ray"], "hit_fraction": model["hit_fraction"], "byte_model": model_src}
         print(json.dumps(out), flush=True)
 
     if args.verify and rank == 0:

@@ -143,7 +143,7 @@ struct Builder {
             if (best_axis >= 0) {
                 // SAH: split cost Ctrav + (Al*Nl + Ar*Nr)/A against leaf cost N
                 float parent_area = bounds.half_area();
-                float split_cost = 1.0f + (parent_area > 0.0f ? best_cost / parent_area : (float)count);
+                float split_cost = opt.traversal_cost + (parent_area > 0.0f ? best_cost / parent_area : (float)count);
                 if (count <= opt.max_leaf && (float)count <= split_cost) { make_leaf(node, first, count, depth); return; }
                 const float ext = cbounds.hi[best_axis] - cbounds.lo[best_axis];
                 const float k1 = (float)NB / ext, c0 = cbounds.lo[best_axis];

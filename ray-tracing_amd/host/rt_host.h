@@ -63,6 +63,7 @@ struct BvhBuildOptions {
     uint32_t max_depth = 48;
     uint32_t bins = 16;
     uint32_t threads = 0;  // 0 = min(hardware_concurrency, 16)
+    float traversal_cost = 1.0f;   // SAH: cost of one node step in units of one primitive test
 };
 
 // boxes[i] bounds primitive i.  n may be 0 (empty tree: one empty leaf).

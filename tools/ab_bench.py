@@ -14,7 +14,8 @@ ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--variants", default="0,1")
 ap.add_argument("--count", action="store_true")
 ap.add_argument("--bounces", type=int, default=-1)
-ap.add_argument("--bvh", default="", help="max_leaf,bins builder options")
+ap.add_argument("--bvh", default="", help="max_leaf,bins[,traversal_cost*16] builder options")
+ap.add_argument("--bvh-sweep", default="", help="semicolon-separated builder option sets: one context each, interleaved")
 ap.add_argument("--stride", default="", help="comma-separated node strides (3,4): one context each, variant 2, interleaved")
 ap.add_argument("--tune", default="", help="semicolon-separated weight sets for variant 2, e.g. 4,4,4,4;4,4,2,4")
 args = ap.parse_args()
@@ -25,11 +26,13 @@ syn = None
 if cfg["scene"].startswith("synth:"):
     from ray_tracing_amd import synth
     syn = synth.load_config_scene(cfg, ROOT)
-def make_ctx(stride=0):
+def make_ctx(stride=0, bvh=None):
     ctx = rt.Context(0)
-    if args.bvh:
-        ml, bins = (int(x) for x in args.bvh.split(","))
-        ctx.set_option(106, ml); ctx.set_option(107, bins)
+    bvh = bvh or args.bvh
+    if bvh:
+        o = [int(x) for x in bvh.split(",")]
+        ctx.set_option(106, o[0]); ctx.set_option(107, o[1])
+        if len(o) > 2: ctx.set_option(110, o[2])
     ctx.set_option(rt.RT_OPT_NODE_STRIDE, stride)
     if syn is not None:
         ctx.scene_upload(syn.vertices, syn.indices, syn.primitives, syn.models)
@@ -71,6 +74,19 @@ if args.stride:
             if r > 0: res[sd].append(ms)
     for sd in strides:
         print(f"node stride {sd * 16} B: median {np.median(res[sd]):.3f} ms min {min(res[sd]):.3f}")
+if args.bvh_sweep:
+    sets = args.bvh_sweep.split(";")
+    ctxs = {b: make_ctx(0, b) for b in sets}
+    res = {b: [] for b in sets}
+    for r in range(args.rounds + 1):
+        for b in sets:
+            ctxs[b].dispatch(u)
+            ms = ctxs[b].last_dispatch_ms()
+            if r > 0: res[b].append(ms)
+    for b in sets:
+        c = ctxs[b]
+        c.set_option(rt.RT_OPT_COUNT_TRAVERSAL, 1); c.stats_reset(); c.dispatch(u); st = c.stats()
+        print(f"bvh {b}: median {np.median(res[b]):.3f} ms min {min(res[b]):.3f} | nodes/ray {st.node_visits / st.rays:.2f} tris/ray {st.triangle_tests / st.rays:.2f} bvh_nodes {st.bvh_nodes}")
 if args.tune:
     ctx.set_option(rt.RT_OPT_KERNEL, 2)
     sets = [[int(x) for x in t.split(",")] for t in args.tune.split(";")]
