@@ -97,6 +97,9 @@ def main():
     W, H = cfg["width"], cfg["height"]
 
     ctx = rt.Context(device_index)
+    for kv in filter(None, os.environ.get("RT_BENCH_OPTIONS", "").split(",")):     # developer knob: "key=value,..." for rt_set_option
+        k, v = kv.split("=")
+        ctx.set_option(int(k), int(v))
     if cfg["scene"].startswith("synth:"):
         synth = __import__("ray_tracing_amd.synth", fromlist=["x"])
         syn = synth.load_config_scene(cfg, ROOT)

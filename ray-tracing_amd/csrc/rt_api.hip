@@ -105,6 +105,7 @@ struct rt_context {
     uint64_t stage_elems = 0;
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
     float sah_traversal_cost = 1.0f; // key 110, in 1/16
+    uint32_t bvh_max_depth = 0;      // key 111, 0 = builder default
     uint64_t stage_budget = 4ull << 30;   // bytes of staging a multi-frame launch may use (key 109, tests)
     uint32_t chunk = 64;             // queue grain: small enough that the last chunk is not a long tail
     bool timed = false;
@@ -321,6 +322,7 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
         if (ctx->tune[6] > 0) opt.max_leaf = (uint32_t)ctx->tune[6];
         if (ctx->tune[7] > 0) opt.bins = (uint32_t)ctx->tune[7];
         opt.traversal_cost = ctx->sah_traversal_cost;
+        if (ctx->bvh_max_depth > 0) opt.max_depth = ctx->bvh_max_depth;
         rt_host::build_bvh2(boxes.data(), n_prims, opt, bvh);
         ctx->bvh_prims = n_prims;
         ctx->rebuilds++;
@@ -560,6 +562,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
         default:
             if (key >= 100 && key < 108) { ctx->tune[key - 100] = (int32_t)value; return RT_OK; }
             if (key == 108 && value >= 1 && value <= 65536) { ctx->chunk = (uint32_t)value; return RT_OK; }
+            if (key == 111 && value >= 0 && value <= 48) { ctx->bvh_max_depth = (uint32_t)value; return RT_OK; }
             if (key == 110 && value >= 0) { ctx->sah_traversal_cost = (float)value / 16.0f; return RT_OK; }
             if (key == 109 && value >= 1) { ctx->stage_budget = (uint64_t)value << 10; return RT_OK; }   // KiB
             return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);
