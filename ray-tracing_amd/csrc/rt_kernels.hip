@@ -36,6 +36,9 @@ constexpr int kBlock = 256;                  // 4 waves per workgroup
 #ifndef RT_NODE_REPS
 #define RT_NODE_REPS 3                       // node steps per scheduling decision
 #endif
+#ifndef RT_GUIDED_FACTOR
+#define RT_GUIDED_FACTOR 8u
+#endif
 #ifndef RT_PHASED_WAVES
 #define RT_PHASED_WAVES 5                    // waves per SIMD the phased kernel is register-budgeted for
 #endif
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 uint32_t grain = P.chunk;
                 if (lane == 0) {
                     const uint32_t seen = __hip_atomic_load(&P.queue->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (seen < total_slots && total_slots - seen > gridDim.x * (kBlock / 64u) * P.chunk * 8u) grain = P.chunk * 4u;
+                    if (seen < total_slots && total_slots - seen > gridDim.x * (kBlock / 64u) * P.chunk * RT_GUIDED_FACTOR) grain = P.chunk * 4u;
                     base = atomicAdd(&P.queue->head, grain);
                 }
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);

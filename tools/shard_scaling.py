@@ -13,6 +13,7 @@ ap.add_argument("--worlds", default="1,2,4,8")
 ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--chunk", type=int, default=0)
 ap.add_argument("--pipeline", type=int, default=1)
+ap.add_argument("--opt", default="", help="key=value,... passed to rt_set_option")
 args = ap.parse_args()
 rt = graft.load_package()
 cfg = graft.load_config(args.config)
@@ -27,10 +28,12 @@ for world in [int(x) for x in args.worlds.split(",")]:
         ctx.scene_finish(scene)
         if args.chunk: ctx.set_option(108, args.chunk)
         ctx.set_option(rt.RT_OPT_FRAME_PIPELINE, args.pipeline)
+        for kv in filter(None, args.opt.split(",")):
+            ctx.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
         ctx.set_shard(rank, world)
         ctx.accum_resize(W, H)
+        ctx.frames_reserve(args.steps)
         ctx.dispatch_frames(u, 1); ctx.sync()
-        ctx.accum_resize(W, H)
         t0 = time.perf_counter()
         ctx.dispatch_frames(u, args.steps); ctx.sync()
         dt = (time.perf_counter() - t0) * 1e3 / args.steps
