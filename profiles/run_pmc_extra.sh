@@ -2,9 +2,9 @@
 # Extra PMC passes: texture-addresser / L1 (TCP) / data-return busy counters.
 # Usage: bash profiles/run_pmc_extra.sh <tag> [config] [steps]
 set -u
-TAG=${1:-x}; CONFIG=${2:-C3}; STEPS=${3:-2}
+TAG=${1:-x}; CONFIG=${2:-C3}; STEPS=${3:-8}
 OUT=$PWD/gpurun_out/prof_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
-CMD="python3 bench.py --config $CONFIG --steps $STEPS --warmup 1 --no-cpu"
+CMD="python3 bench.py --config $CONFIG --steps $STEPS --warmup $STEPS --no-cpu"
 for pass in "TA_BUSY_avr TA_TA_BUSY_sum TD_TD_BUSY_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE" \
             "TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
             "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
