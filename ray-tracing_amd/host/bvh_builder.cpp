@@ -106,35 +106,45 @@ struct Builder {
             int best_axis = -1;
             uint32_t best_bin = 0;
             float best_cost = kInf;
-            Box3 bin_box[32];
-            uint32_t bin_cnt[32];
+            // one pass bins all three axes (the gather of boxes[order[i]] is what costs on big scenes)
+            Box3 bin_box[3][32];
+            uint32_t bin_cnt[3][32];
+            float k1[3], c0[3];
+            bool live[3];
+            for (int ax = 0; ax < 3; ax++) {
+                const float ext = cbounds.hi[ax] - cbounds.lo[ax];
+                live[ax] = ext > 0.0f;
+                k1[ax] = live[ax] ? (float)NB / ext : 0.0f;
+                c0[ax] = cbounds.lo[ax];
+                for (uint32_t i = 0; i < NB; i++) { bin_box[ax][i] = Box3(); bin_cnt[ax][i] = 0; }
+            }
+            for (uint32_t i = first; i < first + count; i++) {
+                const Aabb &b = boxes[order[i]];
+                for (int ax = 0; ax < 3; ax++) {
+                    if (!live[ax]) continue;
+                    int bi = (int)((centroid(b, ax) - c0[ax]) * k1[ax]);
+                    bi = bi < 0 ? 0 : (bi >= (int)NB ? (int)NB - 1 : bi);
+                    bin_cnt[ax][bi]++;
+                    bin_box[ax][bi].grow(b.lo, b.hi);
+                }
+            }
             float right_area[32];
             uint32_t right_cnt[32];
             for (int ax = 0; ax < 3; ax++) {
-                float ext = cbounds.hi[ax] - cbounds.lo[ax];
-                if (!(ext > 0.0f)) continue;
-                for (uint32_t i = 0; i < NB; i++) { bin_box[i] = Box3(); bin_cnt[i] = 0; }
-                const float k1 = (float)NB / ext, c0 = cbounds.lo[ax];
-                for (uint32_t i = first; i < first + count; i++) {
-                    const Aabb &b = boxes[order[i]];
-                    int bi = (int)((centroid(b, ax) - c0) * k1);
-                    bi = bi < 0 ? 0 : (bi >= (int)NB ? (int)NB - 1 : bi);
-                    bin_cnt[bi]++;
-                    bin_box[bi].grow(b.lo, b.hi);
-                }
+                if (!live[ax]) continue;
                 Box3 acc;
                 uint32_t cnt = 0;
                 for (uint32_t i = NB - 1; i > 0; i--) {
-                    acc.grow(bin_box[i]);
-                    cnt += bin_cnt[i];
+                    acc.grow(bin_box[ax][i]);
+                    cnt += bin_cnt[ax][i];
                     right_area[i] = acc.half_area();
                     right_cnt[i] = cnt;
                 }
                 acc = Box3();
                 cnt = 0;
                 for (uint32_t i = 1; i < NB; i++) {
-                    acc.grow(bin_box[i - 1]);
-                    cnt += bin_cnt[i - 1];
+                    acc.grow(bin_box[ax][i - 1]);
+                    cnt += bin_cnt[ax][i - 1];
                     if (cnt == 0 || right_cnt[i] == 0) continue;
                     float cost = acc.half_area() * (float)cnt + right_area[i] * (float)right_cnt[i];
                     if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = i; }
@@ -145,11 +155,10 @@ struct Builder {
                 float parent_area = bounds.half_area();
                 float split_cost = opt.traversal_cost + (parent_area > 0.0f ? best_cost / parent_area : (float)count);
                 if (count <= opt.max_leaf && (float)count <= split_cost) { make_leaf(node, first, count, depth); return; }
-                const float ext = cbounds.hi[best_axis] - cbounds.lo[best_axis];
-                const float k1 = (float)NB / ext, c0 = cbounds.lo[best_axis];
+                const float kb = k1[best_axis], cb0 = c0[best_axis];
                 uint32_t *b = order + first, *e = order + first + count;
                 uint32_t *m = std::partition(b, e, [&](uint32_t id) {
-                    int bi = (int)((centroid(boxes[id], best_axis) - c0) * k1);
+                    int bi = (int)((centroid(boxes[id], best_axis) - cb0) * kb);
                     bi = bi < 0 ? 0 : (bi >= (int)NB ? (int)NB - 1 : bi);
                     return (uint32_t)bi < best_bin;
                 });
