@@ -300,6 +300,11 @@ def test_error_paths(rt, scenes):
         with pytest.raises(rt.RtError) as e:
             ctx.dispatch(u)
         assert e.value.code == -5
+        with pytest.raises(rt.RtError) as e:
+            ctx.frames_reserve(4)                 # no accumulation buffer yet
+        assert e.value.code == -5
+        with pytest.raises(rt.RtError):
+            ctx.set_option(rt.RT_OPT_NODE_STRIDE, 5)
         ctx.accum_resize(8, 8)
         with pytest.raises(rt.RtError) as e:
             ctx.dispatch(u)                       # window != accumulation size
@@ -486,6 +491,8 @@ def test_multi_frame_launch_equals_frame_by_frame(rt, oracle_mod, oracle_scenes,
         ctx.scene_finish(rt.HostScene(scene_path("teapot-circle")))
         ctx.set_shard(rank, world)
         ctx.accum_resize(w, h)
+        if pipeline:
+            ctx.frames_reserve(frames)              # staging allocated here, not inside the dispatch
         u = uniforms_for(rt, cfg, w, h, samples=spp)
         u["frame"], u["accumulation_frame"] = 0, 1
         ctx.dispatch_frames(u, frames)
@@ -499,6 +506,7 @@ def test_multi_frame_launch_equals_frame_by_frame(rt, oracle_mod, oracle_scenes,
     b, st_b = run(0)
     assert st_a.rays == st_b.rays and st_a.pixel_frames == st_b.pixel_frames and st_a.dispatches == st_b.dispatches == frames + 2
     assert st_b.launches == frames + 2 and st_a.launches == (2 if not stage_kib else (frames + 1) // 2 + 1)
+    assert st_a.stack_entries == st_b.stack_entries >= 2 and st_a.resident_blocks > 0
     assert_images_identical(a, b, "pipelined vs frame-by-frame")
     if world == 1:
         want, cnt = oracle_scenes("teapot-circle").render_frames(uniforms_for(oracle_mod, cfg, w, h, samples=spp), frames + 2, mode=1)
