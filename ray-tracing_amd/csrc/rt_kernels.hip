@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
         if (pick == PH_NODE) {
             do {
 #pragma unroll
-              for (int rep = 0; rep < RT_NODE_REPS; rep++)
+                for (int rep = 0; rep < RT_NODE_REPS; rep++) {
                 if (phase == PH_NODE) {
                     if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
                     const float4 *n = nodes + cur;
@@ -646,6 +646,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                     cur = nxt;
                     phase = (int)((uint32_t)nxt >> 31);          // PH_NODE (ref >= 0) or PH_LEAF (ref < 0)
                     if (finished) phase = PH_SHADE;
+                }
                 }
                 pick = schedule();
             } while (pick == PH_NODE);
