@@ -595,3 +595,26 @@ def test_box_test_stays_conservative(rt, oracle_mod, obj_loader, case):
             assert ctx.stats().rays == cnt.rays
             assert np.array_equal(ctx.aov_download(), want_hits), f"{case}: primary hit ids differ from brute force"
             assert_images_identical(ctx.accum_download(), want, f"{case} stride {stride}")
+
+
+@pytest.mark.parametrize("kw", [dict(max_bounces=0, samples=3), dict(max_bounces=1, samples=1), dict(max_bounces=20, samples=2),
+                                dict(max_bounces=4, samples=2, exposure=0.25, environment=3.0),
+                                dict(max_bounces=3, samples=2, fov=0.4), dict(max_bounces=3, samples=2, frame=4000000000, accumulation_frame=7)])
+def test_uniform_fields_are_honoured(rt, oracle_mod, oracle_scenes, ctxs, kw):
+    """Every Uniform field the shader reads (shaders/types.wgsl:1-12): bounce budget 0 / 1 / beyond the reference UI's
+    range, exposure and environment, field of view, a frame counter near u32 wrap with a non-zero accumulation
+    frame (the blend weight 1/(n+1), main.wgsl:30-32, applied to a non-empty buffer)."""
+    cfg = config("C1")
+    w, h = 48, 40
+    ctx = ctxs("cornell-box")
+    ctx.accum_resize(w, h)
+    ctx.stats_reset()
+    first = dict(max_bounces=2, samples=1)                       # something in the buffer for the blend to act on
+    ctx.dispatch(uniforms_for(rt, cfg, w, h, **first))
+    ctx.dispatch(uniforms_for(rt, cfg, w, h, **kw))
+    got, st = ctx.accum_download(), ctx.stats()
+    osc = oracle_scenes("cornell-box")
+    want, _, c1 = osc.render(uniforms_for(oracle_mod, cfg, w, h, **first), mode=1)
+    want, _, c2 = osc.render(uniforms_for(oracle_mod, cfg, w, h, **kw), accum=want, mode=1)
+    assert st.rays == c1.rays + c2.rays
+    assert_images_identical(got, want, str(kw))
