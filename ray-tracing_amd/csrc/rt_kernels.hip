@@ -39,6 +39,9 @@ constexpr int kBlock = 256;                  // 4 waves per workgroup
 #ifndef RT_GUIDED_FACTOR
 #define RT_GUIDED_FACTOR 8u
 #endif
+#ifndef RT_LEAF_REPS
+#define RT_LEAF_REPS 2                       // triangle tests per scheduling decision
+#endif
 #ifndef RT_PHASED_WAVES
 #define RT_PHASED_WAVES 5                    // waves per SIMD the phased kernel is register-budgeted for
 #endif
@@ -652,6 +655,8 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
             } while (pick == PH_NODE);
         } else if (pick == PH_LEAF) {
             do {
+#pragma unroll
+                for (int rep = 0; rep < RT_LEAF_REPS; rep++) {
                 if (phase == PH_LEAF) {
                     // ~cur = first_slot << 3 | triangles left: tested last to first, the count runs down in place
                     uint32_t enc = (uint32_t)~cur;
@@ -669,6 +674,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                             phase = (int)((uint32_t)cur >> 31);
                         }
                     }
+                }
                 }
                 pick = schedule();
             } while (pick == PH_LEAF);
