@@ -100,7 +100,7 @@ struct rt_context {
     bool opt_count = false, opt_aov = false, opt_cw = false, opt_refit = true;
     int opt_node_stride = 0;
     int opt_kernel = 2;
-    int32_t tune[8] = {3, 4, 2, 4, 64, 0, 0, 0};
+    int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE/-/FETCH/-, builder max_leaf, bins
     float4 *d_stage = nullptr;       // per-frame tone-mapped colours of a multi-frame launch (lazy, grows)
     uint64_t stage_elems = 0;
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE

@@ -118,5 +118,5 @@ struct RenderParams {
     float forward[3], right[3], up[3];   // ray_direction's basis (shaders/ray.wgsl:2-4), hoisted to the host
     float aspect, fov_scale;             // ctx.camera.aspect, tan(fov/2) (shaders/ray.wgsl:6-7)
     float scene_abs[3];                  // max |coordinate| of the BVH root box per axis (slab-test error bound)
-    int32_t tune[8];                     // scheduler tunables (experiments)
+    int32_t tune[8];                     // scheduler weights: [0] NODE, [1] LEAF, [2] SHADE, [4] FETCH (others unused by the kernel)
 };

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 // LEAF (has triangles to test), SHADE (trace finished) — and each loop iteration
 // the wave runs ONE phase body, the one most lanes are waiting for (ballot counts).
 // Lanes in other phases sit that iteration out; nobody waits for a whole ray.
-enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_NEXT = 3, PH_FETCH = 4, PH_DONE = 5 };
+enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_FETCH = 4, PH_DONE = 5 };
 
 template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
@@ -601,12 +601,10 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
         const int c_node = __popcll(__ballot(phase == PH_NODE));
         const int c_leaf = __popcll(__ballot(phase == PH_LEAF));
         const int c_shade = __popcll(__ballot(phase == PH_SHADE));
-        const int c_next = __popcll(__ballot(phase == PH_NEXT));
-        if ((c_fetch | c_node | c_leaf | c_shade | c_next) == 0) return PH_DONE;
+        if ((c_fetch | c_node | c_leaf | c_shade) == 0) return PH_DONE;
         int pick = PH_NODE, best_c = c_node * P.tune[0];
         if (c_leaf * P.tune[1] > best_c) { pick = PH_LEAF; best_c = c_leaf * P.tune[1]; }
         if (c_shade * P.tune[2] > best_c) { pick = PH_SHADE; best_c = c_shade * P.tune[2]; }
-        if (c_next * P.tune[3] > best_c) { pick = PH_NEXT; best_c = c_next * P.tune[3]; }
         if (c_fetch * P.tune[4] > best_c) { pick = PH_FETCH; }
         return pick;
     };
@@ -679,7 +677,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 pick = schedule();
             } while (pick == PH_LEAF);
         } else if (pick == PH_SHADE) {
-            // hit or miss shading (main.wgsl:46-69); a path that ends moves on to NEXT or FETCH
+            // hit or miss shading (main.wgsl:46-69); a path that ends starts the pixel's next sample or moves on to FETCH
             if (phase == PH_SHADE) {
                 if (COUNT && first_active_lane()) tl.w_steps++;
                 tl.rays++;
@@ -687,18 +685,10 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                     S.total = S.total + S.light;                    // main.wgsl:26
                     S.sample++;
                     if (S.sample >= P.samples) { phase = PH_FETCH; }
-                    else if (P.tune[5]) { phase = PH_NEXT; }
                     else { new_path(P, C, S); start_trace(); }     // next sample, main.wgsl:36-41
                 } else {
                     start_trace();
                 }
-            }
-            pick = schedule();
-        } else if (pick == PH_NEXT) {
-            // next sample of the same pixel: sample(), main.wgsl:36-41
-            if (phase == PH_NEXT) {
-                new_path(P, C, S);
-                start_trace();
             }
             pick = schedule();
         } else {
@@ -739,8 +729,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                         begin_pixel(P, C, S, x, y, lr, f);
                         have_pixel = true;
                         if (P.samples == 0) { S.total = v3(0.0f, 0.0f, 0.0f); }   // stays in FETCH: written out next round
-                        else if (P.tune[5]) { phase = PH_NEXT; }
-                        else { new_path(P, C, S); start_trace(); }
+                            else { new_path(P, C, S); start_trace(); }
                     }
                 }
                 w_next += take;

@@ -11,8 +11,7 @@ src = mark(src, "            } while (pick == PH_NODE);", "node_end")
 src = mark(src, "        } else if (pick == PH_LEAF) {\n            do {", "leaf_begin")
 src = mark(src, "            } while (pick == PH_LEAF);", "leaf_end")
 src = mark(src, "        } else if (pick == PH_SHADE) {", "shade_begin")
-src = mark(src, "            // pixel boundary: write out finished", "fetch_begin", after=False)
-src = mark(src, "        } else if (pick == PH_NEXT) {", "shade_end", after=False)
+src = mark(src, "            // pixel boundary: write out finished", "shade_end", after=False)
 EXTRA = os.environ.get("ISA_EXTRA", "")   # extra compiler flags to try
 os.makedirs("/tmp/isa", exist_ok=True)
 open("/tmp/isa/marked.hip", "w").write(src)
