@@ -173,7 +173,8 @@ typedef struct RtStats {
 /* rt_set_option keys */
 #define RT_OPT_COUNT_TRAVERSAL 1   /* 0/1: count node visits + triangle tests (slower kernel) */
 #define RT_OPT_AOV             2   /* 0/1: write primary hit ids on every dispatch */
-#define RT_OPT_KERNEL          3   /* kernel variant; 0 = default */
+#define RT_OPT_KERNEL          3   /* kernel variant: 2 (default) lanes scheduled by phase; 0 one ray per lane per step,
+                                      1 one wave per 8x8 tile — both kept for A/B measurements, same bits */
 #define RT_OPT_FRONT_FACE_CW   4   /* 0 (default): CCW = front; 1: CW = front */
 #define RT_OPT_REFIT           5   /* 1 (default): rt_models_update refits the BVH (≙ acceleration_structure.update(),
                                       src/app.rs:61); 0: full rebuild */
@@ -192,6 +193,8 @@ const char *rt_last_error(void);
 /* Use the caller's HIP stream (a hipStream_t) for all device work. NULL = the
  * library's own stream. */
 int rt_set_stream(rt_context *ctx, void *hip_stream);
+/* Keys >= 100 are developer knobs of tools/ (scheduler weights, queue grain, builder parameters); they are not
+ * part of the interface and may change. */
 int rt_set_option(rt_context *ctx, int key, int64_t value);
 
 /* ------------------------------------------------------------------ scene */

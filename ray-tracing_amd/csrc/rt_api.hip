@@ -551,7 +551,10 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
     switch (key) {
         case RT_OPT_COUNT_TRAVERSAL: ctx->opt_count = value != 0; return RT_OK;
         case RT_OPT_AOV: ctx->opt_aov = value != 0; return RT_OK;
-        case RT_OPT_KERNEL: ctx->opt_kernel = (int)value; return RT_OK;
+        case RT_OPT_KERNEL:
+            if (value < 0 || value > 2) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_KERNEL: 0, 1 or 2");
+            ctx->opt_kernel = (int)value;
+            return RT_OK;
         case RT_OPT_FRONT_FACE_CW: ctx->opt_cw = value != 0; return RT_OK;
         case RT_OPT_REFIT: ctx->opt_refit = value != 0; return RT_OK;
         case RT_OPT_FRAME_PIPELINE: ctx->opt_pipeline = value != 0; return RT_OK;
@@ -560,6 +563,8 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             ctx->opt_node_stride = value;
             return RT_OK;
         default:
+            // developer knobs (tools/ab_bench.py, tools/shard_scaling.py): 100..107 scheduler weights and builder leaf size /
+            // bins, 108 queue grain, 109 staging budget in KiB, 110 SAH traversal cost x16, 111 BVH depth cap
             if (key >= 100 && key < 108) { ctx->tune[key - 100] = (int32_t)value; return RT_OK; }
             if (key == 108 && value >= 1 && value <= 65536) { ctx->chunk = (uint32_t)value; return RT_OK; }
             if (key == 111 && value >= 0 && value <= 48) { ctx->bvh_max_depth = (uint32_t)value; return RT_OK; }
