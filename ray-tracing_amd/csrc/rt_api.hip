@@ -710,9 +710,15 @@ int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames) {
     int r = check_dispatch(ctx, uniform);
     if (r) return r;
     RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    // The phased kernel takes a run of frames in ONE launch (frame-major work queue, per-pixel ordering flags):
-    // the slow tail of a frame, where the last long pixels run on a nearly empty GPU, overlaps the next frame.
-    const uint32_t group_max = frame_group_max(ctx);
+    // The phased kernel takes a run of frames in ONE launch (frame-major work queue, colours staged per frame and
+    // blended in frame order): the slow tail of a frame, where the last long pixels run on a nearly empty GPU,
+    // overlaps the next frame.  If the staging planes cannot be allocated the run falls back to shorter launches.
+    uint32_t group_max = frame_group_max(ctx);
+    if (group_max > n_frames) group_max = n_frames;
+    while (group_max > 1 && ensure_stage(ctx, group_max) != RT_OK) {
+        (void)hipGetLastError();                           // out of memory is not sticky; try half
+        group_max /= 2;
+    }
     uint32_t i = 0;
     while (i < n_frames) {
         const uint32_t group = (n_frames - i < group_max) ? n_frames - i : group_max;
