@@ -247,3 +247,25 @@ def test_app_set_params_invalidates_on_hashed_fields_only(rt):
     assert app.set_params(edited, 2.1) is False
     edited["position"][0] = (3.0, 2.0, 1.0)
     assert app.set_params(edited, 2.2) is True
+
+
+def test_host_half_under_sanitizers(tmp_path):
+    """Scene loader, BVH builder / refit, capture, PNG writer and decoder under ASan + UBSan (host code only;
+    tools/host_sanitize.cpp).  Skipped where g++ cannot link the sanitizer runtimes."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "host_sanitize")
+    host = os.path.join(ROOT, "ray-tracing_amd", "host")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tools", "host_sanitize.cpp")] + [os.path.join(host, f + ".cpp") for f in
+           ("scene_loader", "bvh_builder", "capture", "image_decode")] + ["-lpthread", "-lz", "-o", exe]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    if b.returncode != 0:
+        pytest.skip("sanitizer build unavailable: " + b.stderr[-300:])
+    r = subprocess.run([exe] + [scene_path(n) for n in ("cornell-box", "teapot", "teapot-circle")], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:verify_asan_link_order=0"))
+    if "ASan runtime does not come first" in r.stderr:
+        pytest.skip("a preloaded library precedes the ASan runtime here")
+    assert r.returncode == 0 and "host sanitize run ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
