@@ -176,8 +176,11 @@ typedef struct RtStats {
 #define RT_OPT_KERNEL          3   /* kernel variant: 2 (default) lanes scheduled by phase; 0 one ray per lane per step,
                                       1 one wave per 8x8 tile — both kept for A/B measurements, same bits */
 #define RT_OPT_FRONT_FACE_CW   4   /* 0 (default): CCW = front; 1: CW = front */
-#define RT_OPT_REFIT           5   /* 1 (default): rt_models_update refits the BVH (≙ acceleration_structure.update(),
-                                      src/app.rs:61); 0: full rebuild */
+#define RT_OPT_REFIT           5   /* what rt_models_update does to the BVH (≙ acceleration_structure.update(), src/app.rs:61):
+                                      2 (default) refit on the device: the scene upload keeps the tree's topology there
+                                      (set the option BEFORE the upload), triangle records and node boxes are recomputed
+                                      on the GPU and only the 3x4 transforms and the materials cross PCIe;
+                                      1 refit on the host and upload everything; 0 full rebuild */
 #define RT_OPT_FRAME_PIPELINE  7   /* 1 (default): rt_dispatch_frames renders its frames in one launch, frames of
                                       different pixels overlapping (same bits as frame-by-frame); 0: one launch per frame */
 #define RT_OPT_NODE_STRIDE     6   /* BVH node stride in 16-byte units for the NEXT scene upload: 3 (48 B, tightest),
@@ -222,7 +225,7 @@ int rt_textures_upload(rt_context *ctx, const RtTexture *textures, uint32_t n_te
 /* ≙ App::upload_models, src/app.rs:46-62: re-upload models (materials) and the
  * per-geometry transforms, then rebuild the acceleration structure
  * (acceleration_structure.update()): the tree topology is kept and its boxes
- * are refitted to the moved triangles (RT_OPT_REFIT=0 forces a full rebuild).
+ * are refitted to the moved triangles, on the device by default (RT_OPT_REFIT).
  * transforms may be NULL (= unchanged). */
 int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models,
                      const float *transforms);

@@ -19,9 +19,13 @@
 #include "../host/rt_host.h"
 #include "rt_device.h"
 #include "rt_math.h"
+#include "rt_pack.h"
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
 int rt_persistent_blocks(int device, uint32_t stack_entries);
+hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
+                           uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
+                           RtRefitBox *root_out, hipStream_t stream);
 
 namespace {
 
@@ -77,7 +81,13 @@ struct rt_context {
     uint32_t stack_entries = 1;
     float scene_abs[3] = {0.0f, 0.0f, 0.0f};
     bool have_scene = false;
-    rt_host::Bvh2 bvh;               // kept for refits (rt_models_update)
+    rt_host::Bvh2 bvh;               // kept for host refits (rt_models_update)
+    // device refit (RT_OPT_REFIT = 2): topology + scratch, uploaded with the scene
+    int32_t *d_parent = nullptr;     // per node: parent * 2 + child slot, root -1
+    unsigned int *d_arrived = nullptr;
+    RtRefitBox *d_cbox = nullptr, *d_tribox = nullptr, *d_root = nullptr;
+    float *d_xform = nullptr;        // n_geometries x 12
+    uint32_t node_stride = RT_NODE_CHUNKS;
     uint64_t bvh_prims = 0;
     uint64_t refits = 0, rebuilds = 0;
     double build_seconds = 0.0;
@@ -97,7 +107,8 @@ struct rt_context {
     int persistent_blocks = 0;
     uint64_t dispatches = 0, launches = 0;
 
-    bool opt_count = false, opt_aov = false, opt_cw = false, opt_refit = true;
+    bool opt_count = false, opt_aov = false, opt_cw = false;
+    int opt_refit = 2;               // RT_OPT_REFIT: 0 rebuild, 1 host refit, 2 device refit
     int opt_node_stride = 0;
     int opt_kernel = 2;
     int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE/-/FETCH/-, builder max_leaf, bins
@@ -135,51 +146,19 @@ uint64_t local_rows_for(uint32_t h, uint32_t shard_index, uint32_t shard_count) 
 struct Repacked {
     std::vector<DevNode> nodes;      // node i; uploaded at 16-byte chunk i * node_stride
     uint32_t node_stride = RT_NODE_CHUNKS;
+    std::vector<int32_t> parent;     // node -> parent * 2 + child slot (device refit)
     std::vector<DevTri> tris;
     std::vector<DevShade> shade;
     uint32_t stack_entries = 1;
     float scene_abs[3] = {0.0f, 0.0f, 0.0f};   // max |coordinate| of the padded root box
 };
 
-inline float pad_lo(float v) { return v - (fabsf(v) * 4.76837158e-7f + 1e-30f); }
-inline float pad_hi(float v) { return v + (fabsf(v) * 4.76837158e-7f + 1e-30f); }
+inline float pad_lo(float v) { return rt_pad_lo(v); }
+inline float pad_hi(float v) { return rt_pad_hi(v); }
 
-// x >= 0 → the f16 bit pattern nearest to x from below (up = false) or above (up = true).
-// Above saturates to +inf, below to 65504; a non-zero upper bound is never an f16
-// denormal, so a flush-to-zero mode cannot shrink a box.
-uint32_t f16_directed(double x, bool up) {
-    if (!(x > 0.0)) return 0u;
-    int e;
-    frexp(x, &e);                         // x = m * 2^e, m in [0.5, 1)
-    const int E = e + 14;                 // biased f16 exponent of a normal number
-    uint32_t bits;
-    if (E >= 31) bits = up ? 0x7c00u : 0x7bffu;
-    else if (E <= 0) {                    // denormal range: units of 2^-24
-        const double q = ldexp(x, 24);
-        bits = (uint32_t)(up ? ceil(q) : floor(q));
-    } else {
-        const double q = ldexp(x, 25 - E);            // [1024, 2048)
-        bits = ((uint32_t)(E - 1) << 10) + (uint32_t)(up ? ceil(q) : floor(q));
-    }
-    if (up && bits < 0x0400u) bits = 0x0400u;
-    if (bits > 0x7c00u) bits = 0x7c00u;
-    return bits;
-}
-
-// Both children of one node: padded boxes → lower corner + outward-rounded f16 offsets.
+// Both children of one node: padded boxes → lower corner + outward-rounded f16 offsets (rt_pack.h).
 void set_children(DevNode &n, const rt_host::Aabb &box0, int32_t ref0, const rt_host::Aabb &box1, int32_t ref1) {
-    float lo0[3], hi0[3], lo1[3], hi1[3], lo[3];
-    for (int k = 0; k < 3; k++) {
-        lo0[k] = pad_lo(box0.lo[k]); hi0[k] = pad_hi(box0.hi[k]);
-        lo1[k] = pad_lo(box1.lo[k]); hi1[k] = pad_hi(box1.hi[k]);
-        lo[k] = lo0[k] < lo1[k] ? lo0[k] : lo1[k];
-    }
-    auto pack = [&](const float *clo, const float *chi, int k) {
-        return (f16_directed((double)chi[k] - (double)lo[k], true) << 16) | f16_directed((double)clo[k] - (double)lo[k], false);
-    };
-    n.lox = lo[0]; n.loy = lo[1]; n.loz = lo[2];
-    n.c0x = pack(lo0, hi0, 0); n.c0y = pack(lo0, hi0, 1); n.c0z = pack(lo0, hi0, 2);
-    n.c1x = pack(lo1, hi1, 0); n.c1y = pack(lo1, hi1, 1); n.c1z = pack(lo1, hi1, 2);
+    rt_pack_children(n, box0.lo, box0.hi, box1.lo, box1.hi);
     n.ref0 = ref0; n.ref1 = ref1;
     n.pad = 0;
 }
@@ -252,6 +231,7 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
     for (const auto &n : bvh.nodes) if (n.count == 0) n_inner++;
     out.nodes.resize(n_inner);
     memset(out.nodes.data(), 0, n_inner * sizeof(DevNode));
+    out.parent.assign(n_inner, -1);
     struct Item { uint32_t src, dst; };
     std::vector<Item> todo;
     todo.push_back({0u, 0u});
@@ -264,14 +244,33 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         const rt_host::Bvh2Node &c0 = bvh.nodes[n.left], &c1 = bvh.nodes[n.left + 1];
         int32_t r0, r1;
         uint32_t d0 = 0, d1 = 0;
-        if (c0.count) r0 = leaf_ref(c0); else { d0 = next++; r0 = (int32_t)(d0 * out.node_stride); }
-        if (c1.count) r1 = leaf_ref(c1); else { d1 = next++; r1 = (int32_t)(d1 * out.node_stride); }
+        if (c0.count) r0 = leaf_ref(c0); else { d0 = next++; r0 = (int32_t)(d0 * out.node_stride); out.parent[d0] = (int32_t)(it.dst * 2u); }
+        if (c1.count) r1 = leaf_ref(c1); else { d1 = next++; r1 = (int32_t)(d1 * out.node_stride); out.parent[d1] = (int32_t)(it.dst * 2u + 1u); }
         set_children(d, c0.box, r0, c1.box, r1);
         if (!c1.count) todo.push_back({n.left + 1, d1});
         if (!c0.count) todo.push_back({n.left, d0});
     }
     // a depth-first walk pushes at most one reference per inner node on the path: max_depth entries (+1 spare)
     out.stack_entries = bvh.max_depth + 1;
+}
+
+// models[] → the material records the kernel reads (main.wgsl:53-68)
+void convert_materials(const rt_context &ctx, std::vector<DevMaterial> &mats) {
+    mats.assign(ctx.models.size() ? ctx.models.size() : 1, DevMaterial());
+    memset(mats.data(), 0, mats.size() * sizeof(DevMaterial));
+    for (size_t i = 0; i < ctx.models.size(); i++) {
+        const RtMaterial &m = ctx.models[i].material;
+        DevMaterial &d = mats[i];
+        memcpy(d.diffuse, m.metal.diffuse_color, 12);
+        memcpy(d.specular, m.metal.specular_color, 12);
+        d.specular_probability = m.metal.specular_probability;
+        d.roughness = m.metal.roughness;
+        for (int k = 0; k < 3; k++) d.emitted[k] = m.metal.emission_color[k] * m.metal.emission_strength;  // main.wgsl:56
+        d.refractive_index = m.refractive_index;
+        d.tag = m.tag;
+        d.diffuse_texture = m.metal.diffuse_texture;
+        d.normal_texture = m.metal.normal_texture;
+    }
 }
 
 int build_and_upload(rt_context *ctx, bool allow_refit = false) {
@@ -313,7 +312,7 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
         for (int k = 0; k < 3; k++) { boxes[n_tris + i].lo[k] = sp.center[k] - r; boxes[n_tris + i].hi[k] = sp.center[k] + r; }
     }
     rt_host::Bvh2 &bvh = ctx->bvh;
-    if (allow_refit && ctx->opt_refit && ctx->bvh_prims == n_prims && n_prims > 0) {
+    if (allow_refit && ctx->opt_refit != 0 && ctx->bvh_prims == n_prims && n_prims > 0) {
         // ≙ acceleration_structure.update(), src/app.rs:61: same primitives, moved
         rt_host::refit_bvh2(boxes.data(), bvh);
         ctx->refits++;
@@ -335,21 +334,8 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     repack(bvh, corners, ids, *ctx, rp);
     ctx->build_seconds = bvh.build_seconds;
 
-    std::vector<DevMaterial> mats(ctx->models.size() ? ctx->models.size() : 1);
-    memset(mats.data(), 0, mats.size() * sizeof(DevMaterial));
-    for (size_t i = 0; i < ctx->models.size(); i++) {
-        const RtMaterial &m = ctx->models[i].material;
-        DevMaterial &d = mats[i];
-        memcpy(d.diffuse, m.metal.diffuse_color, 12);
-        memcpy(d.specular, m.metal.specular_color, 12);
-        d.specular_probability = m.metal.specular_probability;
-        d.roughness = m.metal.roughness;
-        for (int k = 0; k < 3; k++) d.emitted[k] = m.metal.emission_color[k] * m.metal.emission_strength;  // main.wgsl:56
-        d.refractive_index = m.refractive_index;
-        d.tag = m.tag;
-        d.diffuse_texture = m.metal.diffuse_texture;
-        d.normal_texture = m.metal.normal_texture;
-    }
+    std::vector<DevMaterial> mats;
+    convert_materials(*ctx, mats);
 
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -367,6 +353,18 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
                            hipMemcpyHostToDevice));
     }
     ctx->node_bytes = node_bytes;
+    ctx->node_stride = rp.node_stride;
+    dev_free(ctx->d_parent); dev_free(ctx->d_arrived); dev_free(ctx->d_cbox); dev_free(ctx->d_tribox); dev_free(ctx->d_root); dev_free(ctx->d_xform);
+    if (ctx->opt_refit == 2 && rp.parent.size() == rp.nodes.size() && rp.nodes.size() > 1) {
+        const size_t nn = rp.nodes.size();
+        RT_HIP(hipMalloc((void **)&ctx->d_parent, nn * sizeof(int32_t)));
+        RT_HIP(hipMalloc((void **)&ctx->d_arrived, nn * sizeof(unsigned int)));
+        RT_HIP(hipMalloc((void **)&ctx->d_cbox, 2 * nn * sizeof(RtRefitBox)));
+        RT_HIP(hipMalloc((void **)&ctx->d_tribox, rp.tris.size() * sizeof(RtRefitBox)));
+        RT_HIP(hipMalloc((void **)&ctx->d_root, sizeof(RtRefitBox)));
+        RT_HIP(hipMalloc((void **)&ctx->d_xform, (ctx->primitives.size() ? ctx->primitives.size() : 1) * 12 * sizeof(float)));
+        RT_HIP(hipMemcpy(ctx->d_parent, rp.parent.data(), nn * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     RT_HIP(hipMemcpy(ctx->d_tris, rp.tris.data(), rp.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_shade, rp.shade.data(), rp.shade.size() * sizeof(DevShade), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
@@ -494,6 +492,36 @@ int check_dispatch(rt_context *ctx, const RtUniform *u) {
     return RT_OK;
 }
 
+// rt_models_update on the device (RT_OPT_REFIT = 2): new triangle records and node boxes without leaving the GPU.
+int device_refit(rt_context *ctx) {
+    auto t0 = std::chrono::steady_clock::now();
+    RT_HIP(hipSetDevice(ctx->device));
+    std::vector<DevMaterial> mats;
+    convert_materials(*ctx, mats);
+    RT_HIP(hipMemcpyAsync(ctx->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice, ctx->stream));
+    const float *xform = nullptr;
+    std::vector<float> resolved;
+    if (!ctx->transforms.empty()) {
+        resolved.resize(12 * ctx->primitives.size());
+        for (size_t g = 0; g < ctx->primitives.size(); g++)      // src/scene.rs:141-147: a geometry names its transform by offset
+            memcpy(&resolved[12 * g], &ctx->transforms[12 * ctx->primitives[g].transformation_offset], 48);
+        RT_HIP(hipMemcpyAsync(ctx->d_xform, resolved.data(), resolved.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        xform = ctx->d_xform;
+    }
+    RT_HIP(rt_launch_refit(ctx->d_tris, ctx->d_shade, xform, ctx->d_tribox, ctx->n_tris, reinterpret_cast<float4 *>(ctx->d_nodes), ctx->node_stride,
+                           ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, ctx->stream));
+    RtRefitBox root;
+    RT_HIP(hipMemcpyAsync(&root, ctx->d_root, sizeof root, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));                   // also keeps `mats` / `resolved` alive long enough
+    for (int k = 0; k < 3; k++) {
+        const float m = fmaxf(fabsf(rt_pad_lo(root.lo[k])), fabsf(rt_pad_hi(root.hi[k])));
+        ctx->scene_abs[k] = m <= 3.0e38f ? m : 3.0e38f;
+    }
+    ctx->refits++;
+    ctx->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -530,6 +558,7 @@ int rt_destroy(rt_context *ctx) {
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
     if (ctx->accum_owned) dev_free(ctx->d_accum);
     dev_free(ctx->d_aov); dev_free(ctx->d_counters); dev_free(ctx->d_queue); dev_free(ctx->d_stage);
+    dev_free(ctx->d_parent); dev_free(ctx->d_arrived); dev_free(ctx->d_cbox); dev_free(ctx->d_tribox); dev_free(ctx->d_root); dev_free(ctx->d_xform);
     dev_free(ctx->d_textures); dev_free(ctx->d_texels);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -556,7 +585,10 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             ctx->opt_kernel = (int)value;
             return RT_OK;
         case RT_OPT_FRONT_FACE_CW: ctx->opt_cw = value != 0; return RT_OK;
-        case RT_OPT_REFIT: ctx->opt_refit = value != 0; return RT_OK;
+        case RT_OPT_REFIT:
+            if (value < 0 || value > 2) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_REFIT: 0, 1 or 2");
+            ctx->opt_refit = (int)value;
+            return RT_OK;
         case RT_OPT_FRAME_PIPELINE: ctx->opt_pipeline = value != 0; return RT_OK;
         case RT_OPT_NODE_STRIDE:
             if (value != 0 && value != 3 && value != 4) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_STRIDE: 0 (auto), 3 or 4");
@@ -638,8 +670,18 @@ int rt_textures_upload(rt_context *ctx, const RtTexture *textures, uint32_t n_te
 int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models, const float *transforms) {
     if (!ctx || (n_models && !models)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_models_update before rt_scene_upload");
+    if (n_models < ctx->primitives.size())
+        return fail(RT_ERR_INVALID_ARGUMENT, "scene: %u models for %zu geometries", n_models, ctx->primitives.size());
+    if (transforms)
+        for (size_t g = 0; g < ctx->primitives.size(); g++)
+            if (ctx->primitives[g].transformation_offset >= ctx->primitives.size())
+                return fail(RT_ERR_INVALID_ARGUMENT, "geometry %zu: transformation_offset out of range", g);
     ctx->models.assign(models, models + n_models);
     if (transforms) ctx->transforms.assign(transforms, transforms + 12ull * ctx->primitives.size());
+    // device refit: same primitives, same tree, and the sphere -> model references still valid
+    bool spheres_ok = true;
+    for (const RtSphere &sp : ctx->spheres) spheres_ok = spheres_ok && sp.model < n_models;
+    if (ctx->opt_refit == 2 && ctx->d_parent && ctx->n_nodes > 1 && spheres_ok) return device_refit(ctx);
     return build_and_upload(ctx, /*allow_refit=*/true);
 }
 

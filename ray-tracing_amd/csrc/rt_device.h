@@ -71,6 +71,11 @@ struct DevTexture {
     uint32_t offset, width, height, pad;
 };
 
+// primitive / child box of the device refit (rt_refit.hip)
+struct RtRefitBox {
+    float lo[3], hi[3];
+};
+
 struct DevCounters {
     unsigned long long rays, pixel_frames, node_visits, triangle_tests;
     unsigned long long wave_node_iters, wave_leaf_iters, wave_steps;

@@ -1,0 +1,65 @@
+// rt_pack.h — how child boxes become a DevNode, shared by the host repack (rt_api.hip) and the device refit
+// (rt_refit.hip) so that both write nodes by the same rules.  Outside the arithmetic contract: the only
+// requirement is that a packed box contains the box it was made from.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+#include "rt_math.h"
+
+// Child boxes are widened by a few ulp so that a hit the triangle test accepts a hair outside its triangle
+// is not culled by the box (tie policy).
+RT_HD float rt_pad_lo(float v) { return v - (fabsf(v) * 4.76837158e-7f + 1e-30f); }
+RT_HD float rt_pad_hi(float v) { return v + (fabsf(v) * 4.76837158e-7f + 1e-30f); }
+
+// x >= 0 → the f16 bit pattern nearest to x from below (up = false) or above (up = true).
+// Above saturates to +inf, below to 65504; a non-zero upper bound is never an f16
+// denormal, so a flush-to-zero mode cannot shrink a box.
+RT_HD uint32_t rt_f16_directed(double x, bool up) {
+    if (!(x > 0.0)) return 0u;
+    int e;
+    frexp(x, &e);                         // x = m * 2^e, m in [0.5, 1)
+    const int E = e + 14;                 // biased f16 exponent of a normal number
+    uint32_t bits;
+    if (E >= 31) bits = up ? 0x7c00u : 0x7bffu;
+    else if (E <= 0) {                    // denormal range: units of 2^-24
+        const double q = ldexp(x, 24);
+        bits = (uint32_t)(up ? ceil(q) : floor(q));
+    } else {
+        const double q = ldexp(x, 25 - E);            // [1024, 2048)
+        bits = ((uint32_t)(E - 1) << 10) + (uint32_t)(up ? ceil(q) : floor(q));
+    }
+    if (up && bits < 0x0400u) bits = 0x0400u;
+    if (bits > 0x7c00u) bits = 0x7c00u;
+    return bits;
+}
+
+// Both children of one node: unpadded boxes (lo/hi per child) → lower corner + outward-rounded f16 offsets.
+// References are left alone.
+RT_HD void rt_pack_children(DevNode &n, const float *blo0, const float *bhi0, const float *blo1, const float *bhi1) {
+    float lo0[3], hi0[3], lo1[3], hi1[3], lo[3];
+    for (int k = 0; k < 3; k++) {
+        lo0[k] = rt_pad_lo(blo0[k]); hi0[k] = rt_pad_hi(bhi0[k]);
+        lo1[k] = rt_pad_lo(blo1[k]); hi1[k] = rt_pad_hi(bhi1[k]);
+        lo[k] = lo0[k] < lo1[k] ? lo0[k] : lo1[k];
+    }
+    uint32_t c0[3], c1[3];
+    for (int k = 0; k < 3; k++) {
+        c0[k] = (rt_f16_directed((double)hi0[k] - (double)lo[k], true) << 16) | rt_f16_directed((double)lo0[k] - (double)lo[k], false);
+        c1[k] = (rt_f16_directed((double)hi1[k] - (double)lo[k], true) << 16) | rt_f16_directed((double)lo1[k] - (double)lo[k], false);
+    }
+    n.lox = lo[0]; n.loy = lo[1]; n.loz = lo[2];
+    n.c0x = c0[0]; n.c0y = c0[1]; n.c0z = c0[2];
+    n.c1x = c1[0]; n.c1y = c1[1]; n.c1z = c1[2];
+}
+
+// geometry transform of one corner, the host's expression (host/bvh_builder.cpp gather_triangles): every
+// product and sum rounds once (this file is compiled with -ffp-contract=off on both sides)
+RT_HD void rt_transform_point(const float *m, const float *v, float *dst) {
+    for (int r = 0; r < 3; r++) {
+        float acc = m[4 * r] * v[0] + m[4 * r + 1] * v[1];
+        acc = acc + m[4 * r + 2] * v[2];
+        dst[r] = acc + m[4 * r + 3];
+    }
+}

@@ -1,0 +1,107 @@
+// rt_refit.hip — BVH refit on the device: ≙ acceleration_structure.update(), /root/reference/src/app.rs:61,
+// after App::upload_models moved the geometries (src/app.rs:46-62).
+//
+// The tree keeps its topology.  Kernel 1 re-derives every triangle record from the untransformed corner
+// positions the shading records already hold (DevShade p0..p2) and the geometry's 3x4 transform, with the host's
+// expression (rt_pack.h rt_transform_point: same bits as a host rebuild), and leaves each primitive's box.
+// Kernel 2 starts one thread per node that has a leaf child and walks towards the root; at every node the
+// second arrival (atomic counter) packs both child boxes into the node (rt_pack.h, the host's packing rules)
+// and carries their union up.  RT_OPT_REFIT = 2 selects this path; 1 is the host refit it is tested against.
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+#include "rt_math.h"
+#include "rt_pack.h"
+
+namespace {
+
+__device__ __forceinline__ void grow(RtRefitBox &b, const RtRefitBox &o) {
+    for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], o.lo[k]); b.hi[k] = fmaxf(b.hi[k], o.hi[k]); }
+}
+
+__global__ __launch_bounds__(256) void rt_refit_tris(DevTri *__restrict__ tris, const DevShade *__restrict__ shade,
+                                                     const float *__restrict__ xform, RtRefitBox *__restrict__ tribox, uint64_t n_slots) {
+    const uint64_t slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (slot >= n_slots) return;
+    DevTri t = tris[slot];
+    RtRefitBox b;
+    if (t.is_sphere) {
+        // spheres do not move with a geometry; the box is the builder's (rt_api.hip build_and_upload)
+        const float r = t.e1x * 1.0001f + 1e-6f;
+        const float c[3] = {t.ax, t.ay, t.az};
+        for (int k = 0; k < 3; k++) { b.lo[k] = c[k] - r; b.hi[k] = c[k] + r; }
+    } else {
+        const DevShade &s = shade[slot];
+        float c[9];
+        if (xform) {
+            const float *m = xform + 12u * (size_t)s.geometry;
+            rt_transform_point(m, s.p0, c);
+            rt_transform_point(m, s.p1, c + 3);
+            rt_transform_point(m, s.p2, c + 6);
+        } else {
+            for (int k = 0; k < 3; k++) { c[k] = s.p0[k]; c[3 + k] = s.p1[k]; c[6 + k] = s.p2[k]; }
+        }
+        t.ax = c[0]; t.ay = c[1]; t.az = c[2];
+        t.e1x = c[3] - c[0]; t.e1y = c[4] - c[1]; t.e1z = c[5] - c[2];
+        t.e2x = c[6] - c[0]; t.e2y = c[7] - c[1]; t.e2z = c[8] - c[2];
+        tris[slot] = t;
+        for (int k = 0; k < 3; k++) {
+            b.lo[k] = fminf(c[k], fminf(c[3 + k], c[6 + k]));
+            b.hi[k] = fmaxf(c[k], fmaxf(c[3 + k], c[6 + k]));
+        }
+    }
+    tribox[slot] = b;
+}
+
+__global__ __launch_bounds__(256) void rt_refit_nodes(float4 *__restrict__ chunks, uint32_t stride, const int32_t *__restrict__ parent,
+                                                      unsigned int *__restrict__ arrived, RtRefitBox *cbox, const RtRefitBox *__restrict__ tribox,
+                                                      uint32_t n_nodes, uint64_t n_slots, RtRefitBox *root_out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_nodes) return;
+    const DevNode *nd = reinterpret_cast<const DevNode *>(chunks + (size_t)i * stride);
+    const int32_t refs[2] = {nd->ref0, nd->ref1};
+    uint32_t arrivals = 0;
+    for (int child = 0; child < 2; child++) {
+        if (refs[child] >= 0) continue;
+        const uint32_t enc = (uint32_t)~refs[child];
+        const uint64_t first = enc >> 3;
+        const uint32_t count = enc & 7u;
+        RtRefitBox b;
+        for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; }
+        for (uint32_t k = 0; k < count && first + k < n_slots; k++) grow(b, tribox[first + k]);
+        cbox[2u * (size_t)i + child] = b;
+        arrivals++;
+    }
+    if (arrivals == 0) return;
+    uint32_t cur = i;
+    for (;;) {
+        if (arrivals < 2u) {
+            __threadfence();                                        // my box is visible before I count as arrived
+            if (atomicAdd(&arrived[cur], 1u) == 0u) return;         // the sibling's side finishes this node
+            __threadfence();                                        // and its box is visible to me
+        }
+        const RtRefitBox b0 = cbox[2u * (size_t)cur], b1 = cbox[2u * (size_t)cur + 1u];
+        DevNode *cn = reinterpret_cast<DevNode *>(chunks + (size_t)cur * stride);
+        rt_pack_children(*cn, b0.lo, b0.hi, b1.lo, b1.hi);
+        RtRefitBox u = b0;
+        grow(u, b1);
+        const int32_t p = parent[cur];
+        if (p < 0) { *root_out = u; return; }
+        cbox[(size_t)p] = u;                                        // p = parent node * 2 + child slot
+        cur = (uint32_t)p >> 1;
+        arrivals = 1u;
+    }
+}
+
+}  // namespace
+
+hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
+                           uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
+                           RtRefitBox *root_out, hipStream_t stream) {
+    if (n_slots == 0 || n_nodes == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(arrived, 0, (size_t)n_nodes * sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    rt_refit_tris<<<dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream>>>(tris, shade, xform, tribox, n_slots);
+    rt_refit_nodes<<<dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream>>>(chunks, stride, parent, arrived, cbox, tribox, n_nodes, n_slots, root_out);
+    return hipGetLastError();
+}

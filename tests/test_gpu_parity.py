@@ -618,3 +618,68 @@ def test_uniform_fields_are_honoured(rt, oracle_mod, oracle_scenes, ctxs, kw):
     want, _, c2 = osc.render(uniforms_for(oracle_mod, cfg, w, h, **kw), accum=want, mode=1)
     assert st.rays == c1.rays + c2.rays
     assert_images_identical(got, want, str(kw))
+
+
+def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes):
+    """RT_OPT_REFIT = 2: rt_models_update recomputes the triangle records and the node boxes ON the device
+    (csrc/rt_refit.hip).  Same hit ids and image as the oracle for the moved geometry and as the host refit,
+    over several updates in a row (the arrival counters are reused), with a material edit riding along, on a
+    scene whose transforms were NOT given at upload, and on a scene with spheres in the tree."""
+    cfg = config("C2")
+    w, h = 80, 45
+    s = scenes("teapot")
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(s.primitives), 1))
+    moves = []
+    for k in range(3):
+        m = ident.copy()
+        m[0] = [0.7 + 0.1 * k, 0.2, 0, 0.5, -0.2, 0.9, 0, 0.3 - 0.2 * k, 0, 0, 1.2, -0.4]
+        m[2] = [1, 0, 0, 0.2 * k, 0, 1, 0, -0.1, 0, 0, 1, 0.3]
+        moves.append(m)
+    models = s.models.copy()
+    models["diffuse_color"][0] = (0.9, 0.1, 0.1)                        # upload_models also re-uploads the materials
+    edited = obj_loader.Scene(s.vertices, s.indices, s.primitives, models)
+    u_o, u_r = uniforms_for(oracle_mod, cfg, w, h, samples=3), uniforms_for(rt, cfg, w, h, samples=3)
+    with rt.Context(0) as dev, rt.Context(0) as host:
+        for ctx, mode in ((dev, 2), (host, 1)):
+            ctx.set_option(rt.RT_OPT_REFIT, mode)                       # before the upload: it keeps the topology on the device
+            ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)   # no transforms at upload
+            ctx.set_option(rt.RT_OPT_AOV, 1)
+        for k, m in enumerate(moves):
+            want, want_hits, cnt = oracle_mod.OracleScene(edited, transforms=m).render(u_o, mode=1, want_hits=True)
+            imgs = []
+            for ctx in (dev, host):
+                ctx.models_update(models, transforms=m)
+                ctx.accum_resize(w, h)
+                ctx.stats_reset()
+                ctx.dispatch(u_r)
+                assert ctx.stats().rays == cnt.rays
+                assert np.array_equal(ctx.aov_download(), want_hits), f"update {k}: primary hit ids differ"
+                imgs.append(ctx.accum_download())
+            assert_images_identical(imgs[0], want, f"device refit, update {k}")
+            assert_images_identical(imgs[1], imgs[0], f"host refit vs device refit, update {k}")
+        assert dev.stats().bvh_refits == 3 and dev.stats().bvh_rebuilds == 1
+    # spheres share the tree and do not move; brute force is the judge here
+    import __graft_entry__ as graft
+    graft.load_package()
+    from ray_tracing_amd import synth
+    syn = synth.lattice_scene(scene_path("teapot"), 7, 120, seed=3)
+    cam = syn.camera
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(syn.primitives), 1))
+    moved = ident.copy()
+    moved[:, 3] += 0.35
+    moved[:, 0] = 1.1
+    kw = dict(max_bounces=4, samples=2)
+    osc = oracle_mod.OracleScene(obj_loader.Scene(syn.vertices, syn.indices, syn.primitives, syn.models), transforms=moved, spheres=syn.spheres)
+    want, want_hits, cnt = osc.render(oracle_mod.make_uniform(64, 36, cam["position"], cam["yaw"], cam["pitch"], **kw), mode=0, want_hits=True)
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.RT_OPT_REFIT, 2)
+        ctx.scene_upload(syn.vertices, syn.indices, syn.primitives, syn.models)
+        ctx.spheres_upload(syn.spheres)
+        ctx.set_option(rt.RT_OPT_AOV, 1)
+        ctx.models_update(syn.models, transforms=moved)
+        assert ctx.stats().bvh_refits == 1
+        ctx.accum_resize(64, 36)
+        ctx.dispatch(rt.make_uniform(64, 36, cam["position"], cam["yaw"], cam["pitch"], **kw))
+        assert ctx.stats().rays == cnt.rays
+        assert np.array_equal(ctx.aov_download(), want_hits)
+        assert_images_identical(ctx.accum_download(), want, "device refit with spheres")
