@@ -63,7 +63,10 @@ for it in range(args.iters):
     cam = centre + (rng.random(3) - 0.5) * 3 * spread
     kw = dict(max_bounces=int(rng.integers(0, 6)), samples=int(rng.integers(1, 4)), fov=float(rng.uniform(0.3, 2.5)),
               flags=int(rng.integers(0, 2)), frame=int(rng.integers(1, 2**32)))
-    yaw, pitch = float(rng.uniform(0, 6.28)), float(rng.uniform(-1.2, 1.2))
+    d = centre - cam                                     # look at the soup (ray.wgsl:52-58), with some jitter
+    d = d / max(np.linalg.norm(d), 1e-20)
+    yaw = float(np.arctan2(d[2], d[0]) + rng.uniform(-0.3, 0.3))
+    pitch = float(np.clip(np.arcsin(d[1]) + rng.uniform(-0.3, 0.3), -1.5, 1.5))
     scene = obj_loader.Scene(V, I, P, M)
     want, want_hits, cnt = oracle.OracleScene(scene, transforms=T, build_bvh=False).render(
         oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=0, want_hits=True)
