@@ -10,9 +10,12 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/rt_abi.h"
@@ -147,6 +150,7 @@ struct Repacked {
     std::vector<DevNode> nodes;      // node i; uploaded at 16-byte chunk i * node_stride
     uint32_t node_stride = RT_NODE_CHUNKS;
     std::vector<int32_t> parent;     // node -> parent * 2 + child slot (device refit)
+    bool refit_sources_agree = true; // shading-record corners == BLAS corners (see repack)
     std::vector<DevTri> tris;
     std::vector<DevShade> shade;
     uint32_t stack_entries = 1;
@@ -172,7 +176,12 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
     out.shade.resize(n_tris ? n_tris : 1);
     memset(out.tris.data(), 0, out.tris.size() * sizeof(DevTri));
     memset(out.shade.data(), 0, out.shade.size() * sizeof(DevShade));
-    for (uint64_t slot = 0; slot < n_tris; slot++) {
+    // The device refit (rt_refit.hip) rebuilds a triangle from the corner positions in its shading record, which come
+    // from the MODEL's vertex/index ranges (main.wgsl:86-91), while the BLAS takes them from the GeometryPrimitive's
+    // (src/scene.rs:141-147).  The reference makes the two the same; a caller that does not gets the host refit.
+    std::atomic<bool> sources_agree{true};
+    auto fill = [&](uint64_t slot_lo, uint64_t slot_hi) {
+    for (uint64_t slot = slot_lo; slot < slot_hi; slot++) {
         const uint32_t gid = bvh.order[slot];
         DevTri &t = out.tris[slot];
         if (gid >= n_real_tris) {
@@ -208,7 +217,22 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         memcpy(s.p2, v[2]->position, 12); s.n2x = v[2]->normal[0]; s.n2y = v[2]->normal[1]; s.n2z = v[2]->normal[2]; memcpy(s.uv2, v[2]->uv, 8);
         s.geometry = g;
         s.primitive = p;
+        const RtGeometryPrimitive &gp = ctx.primitives[g];
+        for (int j = 0; j < 3; j++)
+            if (memcmp(ctx.vertices[gp.first_vertex + ctx.indices[gp.first_index + 3u * p + j]].position, v[j]->position, 12) != 0)
+                sources_agree.store(false, std::memory_order_relaxed);
     }
+    };
+    {
+        // records are independent: spread big scenes over the host threads
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const unsigned parts = n_tris >= (1u << 18) ? hw : 1u;
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < parts; k++) th.emplace_back(fill, n_tris * k / parts, n_tris * (k + 1) / parts);
+        fill(0, n_tris / parts);
+        for (auto &t : th) t.join();
+    }
+    out.refit_sources_agree = sources_agree.load();
 
     auto leaf_ref = [&](const rt_host::Bvh2Node &n) { return dev_leaf_ref(n.left, n.count); };
     const rt_host::Bvh2Node &root = bvh.nodes[0];
@@ -355,7 +379,7 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     ctx->node_bytes = node_bytes;
     ctx->node_stride = rp.node_stride;
     dev_free(ctx->d_parent); dev_free(ctx->d_arrived); dev_free(ctx->d_cbox); dev_free(ctx->d_tribox); dev_free(ctx->d_root); dev_free(ctx->d_xform);
-    if (ctx->opt_refit == 2 && rp.parent.size() == rp.nodes.size() && rp.nodes.size() > 1) {
+    if (ctx->opt_refit == 2 && rp.refit_sources_agree && rp.parent.size() == rp.nodes.size() && rp.nodes.size() > 1) {
         const size_t nn = rp.nodes.size();
         RT_HIP(hipMalloc((void **)&ctx->d_parent, nn * sizeof(int32_t)));
         RT_HIP(hipMalloc((void **)&ctx->d_arrived, nn * sizeof(unsigned int)));

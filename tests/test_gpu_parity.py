@@ -683,3 +683,33 @@ def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes):
         assert ctx.stats().rays == cnt.rays
         assert np.array_equal(ctx.aov_download(), want_hits)
         assert_images_identical(ctx.accum_download(), want, "device refit with spheres")
+
+
+def test_refit_when_model_and_geometry_ranges_differ(rt, oracle_mod, obj_loader, scenes):
+    """The BLAS reads corners through the GeometryPrimitive ranges (src/scene.rs:141-147), shading reads attributes
+    through the Model ranges (main.wgsl:86-91).  The reference keeps them equal; the interface does not have to.  Here
+    the models point at a second, displaced copy of the vertices: the device refit (which rebuilds triangles from
+    the shading records) must step aside for the host path, and the image must still equal the oracle's."""
+    cfg = config("C2")
+    w, h = 64, 36
+    s = scenes("teapot")
+    n = len(s.vertices)
+    v2 = np.zeros(2 * n, obj_loader.VERTEX_DTYPE)
+    v2[:n] = s.vertices
+    v2[n:] = s.vertices
+    v2["position"][n:] += np.float32(0.125)
+    models = s.models.copy()
+    models["vertex_start"] += n
+    scene = obj_loader.Scene(v2, s.indices, s.primitives, models)
+    moved = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(s.primitives), 1))
+    moved[0] = [0.8, 0, 0, 0.3, 0, 1.1, 0, 0.1, 0, 0, 1, -0.2]
+    want, want_hits, cnt = oracle_mod.OracleScene(scene, transforms=moved).render(uniforms_for(oracle_mod, cfg, w, h, samples=2), mode=1, want_hits=True)
+    with rt.Context(0) as ctx:
+        ctx.scene_upload(v2, s.indices, s.primitives, models)
+        ctx.set_option(rt.RT_OPT_AOV, 1)
+        ctx.models_update(models, transforms=moved)
+        ctx.accum_resize(w, h)
+        ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=2))
+        assert ctx.stats().rays == cnt.rays
+        assert np.array_equal(ctx.aov_download(), want_hits)
+        assert_images_identical(ctx.accum_download(), want, "model ranges != geometry ranges")
