@@ -271,6 +271,10 @@ int rt_sync(rt_context *ctx);
 /* ≙ accumulation_buffer.download_async, src/ui.rs:82.  dst receives
  * local_rows*w elements of 16 B (xyz + pad).  Synchronises. */
 int rt_accum_download(rt_context *ctx, float *dst);
+/* Capture ≙ src/ui.rs:82-93 without the 16-byte-per-pixel download: the `(x*255) as u8` conversion runs on the
+ * device and dst receives local_rows*w*3 bytes, RGB8, row 0 = top.  Same bytes as rt_accum_download followed by
+ * rt_host_capture_rgb8.  Synchronises. */
+int rt_capture_rgb8(rt_context *ctx, uint8_t *dst);
 /* local_rows*w RtHitId elements; requires RT_OPT_AOV=1 before the dispatch. */
 int rt_aov_download(rt_context *ctx, RtHitId *dst);
 int rt_stats(rt_context *ctx, RtStats *out);

@@ -26,6 +26,7 @@
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
 int rt_persistent_blocks(int device, uint32_t stack_entries);
+hipError_t rt_launch_capture(const float *accum, uint8_t *rgb, size_t n_pixels, hipStream_t stream);
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
                            RtRefitBox *root_out, hipStream_t stream);
@@ -819,6 +820,22 @@ int rt_accum_download(rt_context *ctx, float *dst) {
     uint64_t bytes = local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count) * ctx->width * RT_ACCUM_STRIDE_BYTES;
     RT_HIP(hipMemcpyAsync(dst, ctx->d_accum, bytes, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_capture_rgb8(rt_context *ctx, uint8_t *dst) {
+    if (!ctx || !dst) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!ctx->d_accum) return fail(RT_ERR_NO_ACCUM, "no accumulation buffer");
+    RT_HIP(hipSetDevice(ctx->device));
+    const uint64_t n_pixels = local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count) * ctx->width;
+    if (n_pixels == 0) return RT_OK;
+    uint8_t *d_rgb = nullptr;
+    RT_HIP(hipMalloc((void **)&d_rgb, n_pixels * 3));
+    hipError_t e = rt_launch_capture(ctx->d_accum, d_rgb, n_pixels, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, d_rgb, n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_rgb);
+    if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_capture_rgb8: %s", hipGetErrorString(e));
     return RT_OK;
 }
 

@@ -81,3 +81,11 @@ RT_HD float rt_rand(uint32_t &seed) {
 RT_HD uint32_t rt_seed(uint32_t pixel_idx, uint32_t frame) {
     return (pixel_idx * 2479898233u) ^ (frame * 98379842u);
 }
+
+// Capture, src/ui.rs:84-88: `(x * 255.0) as u8` — Rust's float-to-int cast truncates toward zero, saturates, NaN -> 0
+RT_HD uint8_t rt_capture_u8(float x) {
+    const float v = x * 255.0f;
+    if (!(v == v) || v <= 0.0f) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}

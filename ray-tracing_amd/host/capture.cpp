@@ -3,6 +3,7 @@
 //   write_png_rgb8 ≙ src/ui.rs:83,90-92 (PngEncoder, ExtendedColorType::Rgb8)
 //   uniform_default ≙ src/main.rs:73-84 + Camera::default (src/camera.rs:112-123)
 #include "rt_host.h"
+#include "../csrc/rt_math.h"
 
 #include <cstdio>
 #include <cstring>
@@ -12,13 +13,7 @@ namespace rt_host {
 void capture_rgb8(const float *accum16, uint64_t n_pixels, uint8_t *rgb) {
     for (uint64_t i = 0; i < n_pixels; i++) {
         for (int k = 0; k < 3; k++) {
-            float v = accum16[4 * i + k] * 255.0f;
-            // Rust `as u8`: truncate toward zero, saturate, NaN -> 0
-            uint8_t b;
-            if (!(v == v) || v <= 0.0f) b = 0;
-            else if (v >= 255.0f) b = 255;
-            else b = (uint8_t)v;
-            rgb[3 * i + k] = b;
+            rgb[3 * i + k] = rt_capture_u8(accum16[4 * i + k]);
         }
     }
 }

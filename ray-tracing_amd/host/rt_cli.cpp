@@ -55,14 +55,12 @@ int main(int argc, char **argv) {
     u.window[0] = w; u.window[1] = h;
     u.camera.aspect = (float)w / (float)h;                               // src/camera.rs:56
     if (rt_dispatch_frames(ctx, &u, frames)) return die("dispatch");     // ≙ src/app.rs:78-101, `frames` times
-    std::vector<float> img((size_t)w * h * 4);
-    if (rt_accum_download(ctx, img.data())) return die("download");      // ≙ src/ui.rs:82
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    if (rt_capture_rgb8(ctx, rgb.data())) return die("capture");         // ≙ src/ui.rs:82-88, converted on the device
     float ms = 0;
     rt_last_dispatch_ms(ctx, &ms);
     RtStats st;
     rt_stats(ctx, &st);
-    std::vector<uint8_t> rgb((size_t)w * h * 3);
-    rt_host_capture_rgb8(img.data(), (uint64_t)w * h, rgb.data());       // ≙ src/ui.rs:84-88
     if (rt_host_write_png(out.c_str(), rgb.data(), w, h)) return die("png");
     printf("%s: %ux%u, %u spp x %u frames, %llu rays in %.3f ms (%.1f Mrays/s) -> %s\n", scene.c_str(), w, h, u.samples, frames,
            (unsigned long long)st.rays, ms, st.rays / (ms * 1e3), out.c_str());

@@ -618,6 +618,9 @@ def test_uniform_fields_are_honoured(rt, oracle_mod, oracle_scenes, ctxs, kw):
     want, _, c2 = osc.render(uniforms_for(oracle_mod, cfg, w, h, **kw), accum=want, mode=1)
     assert st.rays == c1.rays + c2.rays
     assert_images_identical(got, want, str(kw))
+    # Capture (src/ui.rs:82-93) on the device == the host conversion of the downloaded buffer == the oracle's
+    rgb = ctx.capture_rgb8()
+    assert np.array_equal(rgb.reshape(-1, 3), oracle_mod.capture_rgb8(want)) and np.array_equal(rgb.reshape(-1, 3), rt.capture_rgb8(got))
 
 
 def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes):
