@@ -12,6 +12,7 @@ from oracle import obj_loader, oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--max-tris", type=int, default=400, help="per geometry")
 args = ap.parse_args()
 rt = graft.load_package()
 rng = np.random.default_rng(args.seed)
@@ -22,7 +23,7 @@ for it in range(args.iters):
     centre = (rng.random(3) - 0.5) * 10.0 ** rng.integers(0, 5)
     spread = 10.0 ** rng.uniform(-1, 2)
     for g in range(n_geo):
-        n = int(rng.integers(1, 400))
+        n = int(rng.integers(1, args.max_tris))
         size = spread * 10.0 ** rng.uniform(-2.5, -0.3)
         c = centre + (rng.random((n, 1, 3)) - 0.5) * 2 * spread
         p = (c + (rng.random((n, 3, 3)) - 0.5) * 2 * size).astype(np.float32)
