@@ -716,3 +716,20 @@ def test_refit_when_model_and_geometry_ranges_differ(rt, oracle_mod, obj_loader,
         assert ctx.stats().rays == cnt.rays
         assert np.array_equal(ctx.aov_download(), want_hits)
         assert_images_identical(ctx.accum_download(), want, "model ranges != geometry ranges")
+
+
+def test_degenerate_windows_and_frame_counts(rt):
+    """Zero-width / zero-height windows, zero frames: nothing to render is not an error (the reference's bounds check,
+    main.wgsl:17, simply retires every invocation)."""
+    with rt.Context(0) as ctx:
+        ctx.scene_finish(rt.HostScene(scene_path("cornell-box")))
+        for (w, h) in [(0, 0), (0, 5), (7, 0), (1, 1)]:
+            ctx.accum_resize(w, h)
+            ctx.stats_reset()
+            u = rt.make_uniform(w, h, (0, 15, 14), 4.712, max_bounces=2, samples=1)
+            ctx.dispatch(u)
+            ctx.dispatch_frames(u, 0)
+            ctx.dispatch_frames(u, 3)
+            ctx.sync()
+            assert ctx.accum_download().shape == (h, w, 4) and ctx.capture_rgb8().shape == (h, w, 3)
+            assert ctx.stats().pixel_frames == 4 * w * h
