@@ -726,7 +726,7 @@ def test_degenerate_windows_and_frame_counts(rt):
         for (w, h) in [(0, 0), (0, 5), (7, 0), (1, 1)]:
             ctx.accum_resize(w, h)
             ctx.stats_reset()
-            u = rt.make_uniform(w, h, (0, 15, 14), 4.712, max_bounces=2, samples=1)
+            u = rt.make_uniform(w, h, (0, 15, 14), 4.712, max_bounces=2, samples=1, aspect=1.0)
             ctx.dispatch(u)
             ctx.dispatch_frames(u, 0)
             ctx.dispatch_frames(u, 3)
