@@ -495,7 +495,36 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
         RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
         if (ctx->persistent_blocks == 0) ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries);
     }
+#ifdef RT_TAIL_PROBE
+    const size_t probe_waves = (size_t)(ctx->persistent_blocks > 0 ? ctx->persistent_blocks : 0) * 4;
+    if (ctx->opt_kernel == 2 && n_frames > 1 && probe_waves) {
+        RT_HIP(hipMalloc((void **)&P.probe, probe_waves * 24));
+        RT_HIP(hipMemsetAsync(P.probe, 0, probe_waves * 24, ctx->stream));
+    }
+#endif
     RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->spheres.empty() || ctx->n_textures > 0, ctx->persistent_blocks, ctx->stream));
+#ifdef RT_TAIL_PROBE
+    if (P.probe) {
+        std::vector<unsigned long long> pr(3 * probe_waves), ends;
+        RT_HIP(hipStreamSynchronize(ctx->stream));
+        RT_HIP(hipMemcpy(pr.data(), P.probe, pr.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(P.probe);
+        unsigned long long t0 = ~0ull, d0 = ~0ull;
+        for (size_t w = 0; w < probe_waves; w++) {
+            if (!pr[3 * w]) continue;                     // wave not launched (grid capped by the amount of work)
+            t0 = std::min(t0, pr[3 * w]);
+            if (pr[3 * w + 1]) d0 = std::min(d0, pr[3 * w + 1]);
+            ends.push_back(pr[3 * w + 2]);
+        }
+        if (!ends.empty()) {
+            std::sort(ends.begin(), ends.end());
+            auto ms = [&](unsigned long long t) { return (double)(t - t0) * 1e-5; };
+            auto q = [&](double f) { return ms(ends[(size_t)(f * (double)(ends.size() - 1))]); };
+            fprintf(stderr, "tail probe: %zu waves, queue empty at %.3f ms; waves exit: 10%% %.3f, 50%% %.3f, 90%% %.3f, 99%% %.3f, last %.3f ms\n",
+                    ends.size(), ms(d0), q(0.10), q(0.50), q(0.90), q(0.99), q(1.0));
+        }
+    }
+#endif
     ctx->dispatches += n_frames;
     ctx->launches++;
     return RT_OK;

@@ -124,4 +124,9 @@ struct RenderParams {
     float aspect, fov_scale;             // ctx.camera.aspect, tan(fov/2) (shaders/ray.wgsl:6-7)
     float scene_abs[3];                  // max |coordinate| of the BVH root box per axis (slab-test error bound)
     int32_t tune[8];                     // scheduler weights: [0] NODE, [1] LEAF, [2] SHADE, [4] FETCH (others unused by the kernel)
+#ifdef RT_TAIL_PROBE
+    // developer build (make EXTRA=-DRT_TAIL_PROBE): per wave {start, first empty claim, exit} in 100 MHz ticks,
+    // summarised on stderr after every multi-frame launch (tail of a launch)
+    unsigned long long *probe;
+#endif
 };

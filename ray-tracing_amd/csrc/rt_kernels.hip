@@ -609,6 +609,10 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
         return pick;
     };
 
+#ifdef RT_TAIL_PROBE
+    const unsigned long long t_start = wall_clock64();
+    unsigned long long t_drain = 0;
+#endif
     int pick = schedule();
     while (pick != PH_DONE) {
         if (pick == PH_NODE) {
@@ -713,8 +717,12 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 }
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                 grain = (uint32_t)__builtin_amdgcn_readfirstlane((int)grain);
-                if (base >= total_slots) { drained = true; }
-                else { w_next = base; w_end = min(base + grain, total_slots); }
+                if (base >= total_slots) {
+                    drained = true;
+#ifdef RT_TAIL_PROBE
+                    t_drain = wall_clock64();
+#endif
+                } else { w_next = base; w_end = min(base + grain, total_slots); }
             }
             if (drained) {
                 if (phase == PH_FETCH) phase = PH_DONE;
@@ -737,6 +745,12 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
             pick = schedule();
         }
     }
+#ifdef RT_TAIL_PROBE
+    if (lane == 0 && P.probe) {
+        unsigned long long *pr = P.probe + 3u * (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
+        pr[0] = t_start; pr[1] = t_drain; pr[2] = wall_clock64();
+    }
+#endif
     flush_tally<COUNT>(P, tl);
 }
 
