@@ -682,19 +682,22 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
             } while (pick == PH_LEAF);
         } else if (pick == PH_SHADE) {
             // hit or miss shading (main.wgsl:46-69); a path that ends starts the pixel's next sample or moves on to FETCH
+            do {
             if (phase == PH_SHADE) {
                 if (COUNT && first_active_lane()) tl.w_steps++;
                 tl.rays++;
+                bool more = true;
                 if (shade_core<AOV, SPH>(P, S, best)) {
                     S.total = S.total + S.light;                    // main.wgsl:26
                     S.sample++;
-                    if (S.sample >= P.samples) { phase = PH_FETCH; }
-                    else { new_path(P, C, S); start_trace(); }     // next sample, main.wgsl:36-41
-                } else {
-                    start_trace();
+                    more = S.sample < P.samples;
+                    if (more) new_path(P, C, S);                    // next sample, main.wgsl:36-41
                 }
+                if (more) start_trace();
+                else phase = PH_FETCH;
             }
             pick = schedule();
+            } while (pick == PH_SHADE);
         } else {
             // pixel boundary: write out finished pixel-frames (main.wgsl:27-32), then hand
             // pixel slots of the wave's chunk to the lanes
