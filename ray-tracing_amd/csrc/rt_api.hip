@@ -25,7 +25,7 @@
 #include "rt_pack.h"
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
-int rt_persistent_blocks(int device, uint32_t stack_entries);
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres);
 hipError_t rt_launch_capture(const float *accum, uint8_t *rgb, size_t n_pixels, hipStream_t stream);
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
@@ -108,14 +108,16 @@ struct rt_context {
 
     DevCounters *d_counters = nullptr;
     DevQueue *d_queue = nullptr;
-    int persistent_blocks = 0;
+    int persistent_blocks = 0;       // resident workgroups of the kernel instance `persistent_sel` (0 = not asked yet)
+    int persistent_sel = -1;
+    int cu_count = 0;
     uint64_t dispatches = 0, launches = 0;
 
     bool opt_count = false, opt_aov = false, opt_cw = false;
     int opt_refit = 2;               // RT_OPT_REFIT: 0 rebuild, 1 host refit, 2 device refit
     int opt_node_stride = 0;
     int opt_kernel = 2;
-    int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE/-/FETCH/-, builder max_leaf, bins
+    int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE, workgroups per CU (0 = all that fit), FETCH weight, -, builder max_leaf, bins
     float4 *d_stage = nullptr;       // per-frame tone-mapped colours of a multi-frame launch (lazy, grows)
     uint64_t stage_elems = 0;
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
@@ -493,7 +495,14 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
     P.chunk = ctx->chunk;
     if (ctx->opt_kernel != 1) {
         RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
-        if (ctx->persistent_blocks == 0) ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries);
+        const bool ext = !ctx->spheres.empty() || ctx->n_textures > 0;
+        const int sel = (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
+        if (ctx->persistent_blocks == 0 || ctx->persistent_sel != sel) {
+            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext);
+            ctx->persistent_sel = sel;
+            if (ctx->tune[3] > 0 && ctx->cu_count > 0 && ctx->persistent_blocks > ctx->tune[3] * ctx->cu_count)
+                ctx->persistent_blocks = ctx->tune[3] * ctx->cu_count;       // developer knob 103: workgroups per CU
+        }
     }
 #ifdef RT_TAIL_PROBE
     const size_t probe_waves = (size_t)(ctx->persistent_blocks > 0 ? ctx->persistent_blocks : 0) * 4;
@@ -592,6 +601,7 @@ int rt_create(int device_id, rt_context **out) {
     RT_HIP(hipSetDevice(device_id));
     rt_context *ctx = new rt_context();
     ctx->device = device_id;
+    (void)hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device_id);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc((void **)&ctx->d_counters, sizeof(DevCounters)) != hipSuccess ||
@@ -649,9 +659,13 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             ctx->opt_node_stride = value;
             return RT_OK;
         default:
-            // developer knobs (tools/ab_bench.py, tools/shard_scaling.py): 100..107 scheduler weights and builder leaf size /
+            // developer knobs (tools/ab_bench.py, tools/shard_scaling.py): 100..107 scheduler weights (103: resident workgroups per CU, 0 = all that fit) and builder leaf size /
             // bins, 108 queue grain, 109 staging budget in KiB, 110 SAH traversal cost x16, 111 BVH depth cap
-            if (key >= 100 && key < 108) { ctx->tune[key - 100] = (int32_t)value; return RT_OK; }
+            if (key >= 100 && key < 108) {
+                ctx->tune[key - 100] = (int32_t)value;
+                if (key == 103) ctx->persistent_blocks = 0;     // grid size is recomputed at the next launch
+                return RT_OK;
+            }
             if (key == 108 && value >= 1 && value <= 65536) { ctx->chunk = (uint32_t)value; return RT_OK; }
             if (key == 111 && value >= 0 && value <= 48) { ctx->bvh_max_depth = (uint32_t)value; return RT_OK; }
             if (key == 110 && value >= 0) { ctx->sah_traversal_cost = (float)value / 16.0f; return RT_OK; }

@@ -809,16 +809,27 @@ hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const Ren
 
 }  // namespace
 
-// Persistent grid size: the number of 256-thread workgroups that are resident
-// at once (register/LDS limited), so every wave lives for the whole launch.
-int rt_persistent_blocks(int device, uint32_t stack_entries) {
-    // all persistent variants are launched with this grid; sized for the default (phased) kernel
+// Persistent grid size: the number of 256-thread workgroups of the given kernel
+// instance that are resident at once (register/LDS limited), so every wave
+// lives for the whole launch.
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
     const size_t lds = (size_t)stack_entries * kBlock * sizeof(uint32_t);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rt_render_phased<false, false, false>, kBlock, lds) != hipSuccess || per_cu < 1)
-        per_cu = 4;
+    // the instances differ in register count, hence in how many workgroups fit
+    const void *fn = nullptr;
+    switch ((count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0)) {
+        case 0: fn = (const void *)rt_render_phased<false, false, false>; break;
+        case 1: fn = (const void *)rt_render_phased<false, false, true>; break;
+        case 2: fn = (const void *)rt_render_phased<false, true, false>; break;
+        case 3: fn = (const void *)rt_render_phased<false, true, true>; break;
+        case 4: fn = (const void *)rt_render_phased<true, false, false>; break;
+        case 5: fn = (const void *)rt_render_phased<true, false, true>; break;
+        case 6: fn = (const void *)rt_render_phased<true, true, false>; break;
+        default: fn = (const void *)rt_render_phased<true, true, true>; break;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu * prop.multiProcessorCount;
 }
 

@@ -100,7 +100,7 @@ if args.tune:
             if r > 0: res[i].append(ms)
     for i, ws in enumerate(sets):
         print(f"tune {ws}: median {np.median(res[i]):.3f} ms min {min(res[i]):.3f}")
-    for k, w in enumerate([3, 4, 2, 4, 64, 0]): ctx.set_option(100 + k, w)
+    for k, w in enumerate([3, 4, 2, 0, 64, 0]): ctx.set_option(100 + k, w)
 if args.count:
     for v in variants:
         ctx.set_option(rt.RT_OPT_KERNEL, v)
