@@ -216,8 +216,8 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         for (int j = 0; j < 3; j++) v[j] = &ctx.vertices[m.vertex_start + ctx.indices[is + j]];
         DevShade &s = out.shade[slot];
         memcpy(s.p0, v[0]->position, 12); s.n0x = v[0]->normal[0]; s.n0y = v[0]->normal[1]; s.n0z = v[0]->normal[2]; memcpy(s.uv0, v[0]->uv, 8);
-        memcpy(s.p1, v[1]->position, 12); s.n1x = v[1]->normal[0]; s.n1y = v[1]->normal[1]; s.n1z = v[1]->normal[2]; memcpy(s.uv1, v[1]->uv, 8);
-        memcpy(s.p2, v[2]->position, 12); s.n2x = v[2]->normal[0]; s.n2y = v[2]->normal[1]; s.n2z = v[2]->normal[2]; memcpy(s.uv2, v[2]->uv, 8);
+        memcpy(s.p1, v[1]->position, 12); memcpy(s.n1, v[1]->normal, 12); memcpy(s.uv1, v[1]->uv, 8);
+        memcpy(s.p2, v[2]->position, 12); memcpy(s.n2, v[2]->normal, 12); memcpy(s.uv2, v[2]->uv, 8);
         s.geometry = g;
         s.primitive = p;
         const RtGeometryPrimitive &gp = ctx.primitives[g];

@@ -48,20 +48,26 @@ struct alignas(16) DevTri {
 };
 static_assert(sizeof(DevTri) == 48, "DevTri");
 
+// Chunk order follows use: an untextured hit reads chunks 0-4 (five 16-byte loads: positions, normals, ids);
+// only textured materials read the uv chunks, only spheres read pad0.
 struct alignas(16) DevShade {
-    float p0[3], n0x;  float n0y, n0z, uv0[2];
-    float p1[3], n1x;  float n1y, n1z, uv1[2];
-    float p2[3], n2x;  float n2y, n2z, uv2[2];
-    uint32_t geometry, primitive, pad0, pad1;
+    float p0[3], n0x;                       // vertex 0 position; vertex 0 normal, one component per chunk
+    float p1[3], n0y;
+    float p2[3], n0z;
+    float n1[3]; uint32_t geometry;         // geometry_index (bit 31: sphere record)
+    float n2[3]; uint32_t primitive;        // primitive_index
+    float uv0[2], uv1[2];
+    float uv2[2]; uint32_t pad0, pad1;      // pad0: a sphere's model index
     uint32_t pad2[4];
 };
 static_assert(sizeof(DevShade) == 128, "DevShade");
 
+// Chunk order follows use: the tag comes with the first load; a metal hit reads chunks 0-2, a dielectric one 0 and 3.
 struct alignas(16) DevMaterial {
-    float diffuse[3];  float specular_probability;
-    float specular[3]; float roughness;
-    float emitted[3];  float refractive_index;    // emitted = emission_color * emission_strength (main.wgsl:56)
-    uint32_t tag, diffuse_texture, normal_texture, pad;   // texture ids 1-based, 0 = none (src/scene.rs:170-174)
+    uint32_t tag; float diffuse[3];
+    float specular_probability; float specular[3];
+    float roughness; float emitted[3];            // emitted = emission_color * emission_strength (main.wgsl:56)
+    float refractive_index; uint32_t diffuse_texture, normal_texture, pad;   // texture ids 1-based, 0 = none (src/scene.rs:170-174)
 };
 static_assert(sizeof(DevMaterial) == 64, "DevMaterial");
 

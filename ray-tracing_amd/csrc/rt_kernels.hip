@@ -354,16 +354,15 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
     } else {
         // attribute part of trace_ray, main.wgsl:86-101
         const DevShade *sh = P.shade + h.slot;
-        float4 s0 = ld4(&sh->p0[0]), s1 = ld4(&sh->n0y), s2 = ld4(&sh->p1[0]), s3 = ld4(&sh->n1y),
-               s4 = ld4(&sh->p2[0]), s5 = ld4(&sh->n2y);
-        uint32_t geometry = sh->geometry;
+        const float4 s0 = ld4(&sh->p0[0]), s1 = ld4(&sh->p1[0]), s2 = ld4(&sh->p2[0]), s3 = ld4(&sh->n1[0]), s4 = ld4(&sh->n2[0]);
+        uint32_t geometry = __float_as_uint(s3.w);
         const float b0 = 1.0f - h.u - h.v, b1 = h.u, b2 = h.v;
-        rt_v3 normal = v3(s0.w * b0 + s2.w * b1 + s4.w * b2,
-                          s1.x * b0 + s3.x * b1 + s5.x * b2,
-                          s1.y * b0 + s3.y * b1 + s5.y * b2);
-        rt_v3 position = v3(s0.x * b0 + s2.x * b1 + s4.x * b2,
-                            s0.y * b0 + s2.y * b1 + s4.y * b2,
-                            s0.z * b0 + s2.z * b1 + s4.z * b2);
+        rt_v3 normal = v3(s0.w * b0 + s3.x * b1 + s4.x * b2,
+                          s1.w * b0 + s3.y * b1 + s4.y * b2,
+                          s2.w * b0 + s3.z * b1 + s4.z * b2);
+        rt_v3 position = v3(s0.x * b0 + s1.x * b1 + s2.x * b2,
+                            s0.y * b0 + s1.y * b1 + s2.y * b2,
+                            s0.z * b0 + s1.z * b1 + s2.z * b2);
         if (SPH && (geometry & 0x80000000u)) {
             // sphere: P = o + t d, N = (P - C) / r, front = dot(d, N) < 0; the record
             // holds C in p0, 1/r in n0x and the model index in pad0
@@ -373,20 +372,22 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
             geometry = sh->pad0;
         }
         const DevMaterial *mp = P.materials + geometry;             // models[geometry_index].material
-        float4 m0 = ld4(&mp->diffuse[0]), m1 = ld4(&mp->specular[0]), m2 = ld4(&mp->emitted[0]);
-        const uint32_t tag = mp->tag;
+        const float4 m0 = ld4(&mp->tag), m1 = ld4(&mp->specular_probability), m2 = ld4(&mp->roughness);
+        const uint32_t tag = __float_as_uint(m0.x);
         if (tag == 0u) {                                            // main.wgsl:53-61
             // get_scattered_direction_metal, ray.wgsl:12-32
-            float is_specular = (rt_rand(S.seed) < m0.w) ? 1.0f : 0.0f;
-            float smoothness = 1.0f - m1.w;
+            float is_specular = (rt_rand(S.seed) < m1.x) ? 1.0f : 0.0f;
+            float smoothness = 1.0f - m2.x;
             rt_v3 scatter_normal = normal;
-            rt_v3 diffuse_color = v3(m0.x, m0.y, m0.z);
+            rt_v3 diffuse_color = v3(m0.y, m0.z, m0.w);
             if (SPH && (mp->normal_texture | mp->diffuse_texture) != 0u) {
                 // trace.uv, main.wgsl:96 (spheres: uv = 0)
                 float tu = 0.0f, tv = 0.0f;
-                if (!(sh->geometry & 0x80000000u)) {
-                    tu = s1.z * b0 + s3.z * b1 + s5.z * b2;
-                    tv = s1.w * b0 + s3.w * b1 + s5.w * b2;
+                if (!(__float_as_uint(s3.w) & 0x80000000u)) {
+                    const float4 u01 = ld4(&sh->uv0[0]);
+                    const float2 u2 = *reinterpret_cast<const float2 *>(&sh->uv2[0]);
+                    tu = u01.x * b0 + u01.z * b1 + u2.x * b2;
+                    tv = u01.y * b0 + u01.w * b1 + u2.y * b2;
                 }
                 if (mp->normal_texture > 0u) {                              // ray.wgsl:17-20
                     rt_v3 smp = sample_rgb(P, mp->normal_texture - 1u, tu, tv);
@@ -397,16 +398,17 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
             rt_v3 diffuse = rand_cosine_hemisphere_vector(S.seed, scatter_normal);
             rt_v3 specular = rt_reflect(S.dir, scatter_normal);
             rt_v3 sdir = rt_mix(diffuse, specular, smoothness * is_specular);
-            rt_v3 scol = rt_mix(diffuse_color, v3(m1.x, m1.y, m1.z), is_specular);
-            S.light = S.light + v3(m2.x, m2.y, m2.z) * S.color;
+            rt_v3 scol = rt_mix(diffuse_color, v3(m1.y, m1.z, m1.w), is_specular);
+            S.light = S.light + v3(m2.y, m2.z, m2.w) * S.color;
             S.color = S.color * scol;
             S.pos = position + normal * 0.0001f;
             S.dir = sdir;
         } else if (tag == 1u) {                                     // main.wgsl:62-68
             // get_scattered_direction_dielectric, ray.wgsl:34-49
             rt_v3 n = rt_dot(normal, S.dir) < 0.0f ? normal : -normal;   // faceForward(N, N, dir)
-            float ri = m2.w;
-            if (h.front) ri = 1.0f / m2.w;
+            const float ri_in = mp->refractive_index;
+            float ri = ri_in;
+            if (h.front) ri = 1.0f / ri_in;
             float c = rt_dot(-S.dir, n);
             float cos_theta = (c < 1.0f) ? c : 1.0f;
             float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
