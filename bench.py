@@ -45,13 +45,13 @@ def cpu_baseline_and_byte_model(cfg, sample_w, sample_h):
                             aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]),
                             max_bounces=cfg["max_bounces"], samples=cfg["samples"])
     t0 = time.perf_counter()
-    _, _, cnt = sc.render(u, mode=1)
+    img, _, cnt = sc.render(u, mode=1)
     dt = time.perf_counter() - t0
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     n_node = cnt.node_visits / cnt.rays
     n_tri = cnt.triangle_tests / cnt.rays
     hit = cnt.hits / cnt.rays
-    return {"mrays": cnt.rays / dt / 1e6, "seconds": dt, "rays": cnt.rays, "threads": threads,
+    return {"mrays": cnt.rays / dt / 1e6, "seconds": dt, "rays": cnt.rays, "threads": threads, "image": img,
             "n_node": n_node, "n_tri": n_tri, "hit": hit,
             "bytes_per_ray": n_node * S_NODE + n_tri * S_TRI + hit * S_HIT}
 
@@ -199,6 +199,16 @@ def main():
                                              f"same scene/camera, {cfg['samples']} spp, {cfg['max_bounces']} bounces: {cpu['rays']} rays in {cpu['seconds']:.2f} s"}
             model = {"nodes_per_ray": cpu["n_node"], "tris_per_ray": cpu["n_tri"], "hit_fraction": cpu["hit"]}
             model_src = "measured by this run's cpu_baseline leg"
+            # the oracle frame is also the checker: the same frame from the HIP path (outside the timed region) must
+            # hold the same bits (at the default --cpu-sample that is one full-size frame)
+            ctx.accum_resize(sw, sh)
+            ctx.stats_reset()
+            ctx.dispatch(rt.make_uniform(sw, sh, cfg["position"], cfg["yaw"], cfg["pitch"], aspect=np.float32(W) / np.float32(H),
+                                         max_bounces=cfg["max_bounces"], samples=cfg["samples"]))
+            got = ctx.accum_download()
+            out["parity"] = {"what": f"one {sw}x{sh} frame, HIP accumulation buffer vs oracle, bit for bit",
+                             "identical": bool(np.array_equal(got.view(np.uint32), cpu["image"].view(np.uint32))),
+                             "rays_equal": int(ctx.stats().rays) == int(cpu["rays"])}
         if model is not None:
             bytes_per_ray = model["nodes_per_ray"] * S_NODE + model["tris_per_ray"] * S_TRI + model["hit_fraction"] * S_HIT
             rays_per_launch = rays / launches / world         # per GPU, per launch

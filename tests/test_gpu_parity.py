@@ -416,6 +416,7 @@ def test_bench_contract_and_sharded_image(ranks):
         assert key in m["roofline"]
     if ranks == 1:                                   # the CPU leg runs on rank 0 at N = 1 only
         assert m["cpu_baseline"]["kind"] == "port" and m["cpu_baseline"]["value"] > 0
+        assert m["parity"]["identical"] is True and m["parity"]["rays_equal"] is True
     else:
         assert "cpu_baseline" not in m
 
