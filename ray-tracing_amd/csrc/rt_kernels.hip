@@ -36,6 +36,9 @@ constexpr int kBlock = 256;                  // 4 waves per workgroup
 #ifndef RT_NODE_REPS
 #define RT_NODE_REPS 3                       // node steps per scheduling decision
 #endif
+#ifndef RT_NODE_EARLY_OUT
+#define RT_NODE_EARLY_OUT 2                  // leave the unrolled node steps when under 1/2 of the entering lanes remain (-1 %)
+#endif
 #ifndef RT_GUIDED_FACTOR
 #define RT_GUIDED_FACTOR 8u
 #endif
@@ -619,8 +622,11 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     while (pick != PH_DONE) {
         if (pick == PH_NODE) {
             do {
+                const int node_lanes = __popcll(__ballot(phase == PH_NODE));
 #pragma unroll
                 for (int rep = 0; rep < RT_NODE_REPS; rep++) {
+                // back to the scheduler early once fewer than 1/RT_NODE_EARLY_OUT of the lanes that came in are still on nodes
+                if (rep > 0 && __popcll(__ballot(phase == PH_NODE)) * RT_NODE_EARLY_OUT < node_lanes) break;
                 if (phase == PH_NODE) {
                     if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
                     const float4 *n = nodes + cur;
