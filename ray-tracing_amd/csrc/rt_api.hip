@@ -118,7 +118,7 @@ struct rt_context {
     int opt_node_stride = 0;
     int opt_kernel = 2;
     int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE, workgroups per CU (0 = all that fit), FETCH weight, -, builder max_leaf, bins
-    float4 *d_stage = nullptr;       // per-frame tone-mapped colours of a multi-frame launch (lazy, grows)
+    float4 *d_stage = nullptr;       // per-frame sample sums of a multi-frame launch (lazy, grows)
     uint64_t stage_elems = 0;
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
     float sah_traversal_cost = 1.0f; // key 110, in 1/16

@@ -117,7 +117,7 @@ struct RenderParams {
     uint32_t stack_entries;      // LDS traversal stack depth per lane
     uint32_t chunk;              // pixel slots a wave claims from the queue per atomic
     // Multi-frame launches (phased kernel only): frames frame..frame+n_frames-1 of every pixel in ONE launch.
-    // Work item q = frame_offset * slots + slot; each pixel-frame parks its tone-mapped colour in
+    // Work item q = frame_offset * slots + slot; each pixel-frame parks its sample sum in
     // stage[frame_offset * stage_stride + pixel] and rt_blend_frames folds them into `accum` in frame order.
     uint32_t n_frames;           // >= 1
     uint32_t local_rows;         // rows of `accum`

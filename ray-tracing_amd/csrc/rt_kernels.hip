@@ -316,18 +316,24 @@ __device__ __forceinline__ void begin_pixel(const RenderParams &P, const Camera 
     S.first_ray = true;
 }
 
+// main.wgsl:27-29: mean of the samples, exposure, tone map
+__device__ __forceinline__ rt_v3 resolve_pixel(const RenderParams &P, rt_v3 sum) {
+    const float ns = (float)P.samples;
+    rt_v3 total = v3(sum.x / ns, sum.y / ns, sum.z / ns);
+    return v3(tone_map1(total.x * P.exposure), tone_map1(total.y * P.exposure), tone_map1(total.z * P.exposure));
+}
+
 // main.wgsl:27-32
 __device__ __forceinline__ void finish_pixel(const RenderParams &P, const PixelState &S) {
-    const float ns = (float)P.samples;
-    rt_v3 total = v3(S.total.x / ns, S.total.y / ns, S.total.z / ns);
-    rt_v3 mapped = v3(tone_map1(total.x * P.exposure), tone_map1(total.y * P.exposure), tone_map1(total.z * P.exposure));
     const size_t pix = (size_t)S.local_row * P.width + pixel_x(P, S);
     if (P.n_frames > 1u) {
-        // multi-frame launch: frames of a pixel finish in any order, so the tone-mapped colour is parked
-        // per frame and rt_blend_frames applies main.wgsl:31-32 to them in frame order afterwards
-        P.stage[(size_t)pixel_frame(P, S) * P.stage_stride + pix] = make_float4(mapped.x, mapped.y, mapped.z, 0.0f);
+        // multi-frame launch: frames of a pixel finish in any order, so the sample SUM is parked per frame and
+        // rt_blend_frames applies main.wgsl:27-32 to the frames in order afterwards (with every lane busy, which
+        // the few lanes that end a pixel-frame together here are not)
+        P.stage[(size_t)pixel_frame(P, S) * P.stage_stride + pix] = make_float4(S.total.x, S.total.y, S.total.z, 0.0f);
         return;
     }
+    const rt_v3 mapped = resolve_pixel(P, S.total);
     const float w = 1.0f / (float)(P.accumulation_frame + 1u);
     float4 *dst = reinterpret_cast<float4 *>(P.accum) + pix;
     float4 old = *dst;
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     flush_tally<COUNT>(P, tl);
 }
 
-// Second half of a multi-frame launch: out = mix(old, mapped_f, 1 / (accumulation_frame + f + 1)) for
+// Second half of a multi-frame launch: out = mix(old, tone_map(sum_f / samples * exposure), 1 / (accumulation_frame + f + 1)) for
 // f = 0 .. n_frames-1 in order (main.wgsl:30-32), one thread per pixel, coalesced.
 __global__ __launch_bounds__(256) void rt_blend_frames(const RenderParams P, size_t n_pixels) {
     const size_t pix = (size_t)blockIdx.x * 256u + threadIdx.x;
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(256) void rt_blend_frames(const RenderParams P, siz
     for (uint32_t f = 0; f < P.n_frames; f++) {
         const float4 m = P.stage[(size_t)f * P.stage_stride + pix];
         const float w = 1.0f / (float)(P.accumulation_frame + f + 1u);
-        acc = rt_mix(acc, v3(m.x, m.y, m.z), w);
+        acc = rt_mix(acc, resolve_pixel(P, v3(m.x, m.y, m.z)), w);
     }
     *dst = make_float4(acc.x, acc.y, acc.z, old.w);
 }
