@@ -566,6 +566,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 // the wave runs ONE phase body, the one most lanes are waiting for (ballot counts).
 // Lanes in other phases sit that iteration out; nobody waits for a whole ray.
 enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_FETCH = 4, PH_DONE = 5 };
+constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel-frame that has not started its first path
 
 template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
@@ -699,14 +700,20 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
             do {
             if (phase == PH_SHADE) {
                 if (COUNT && first_active_lane()) tl.w_steps++;
-                tl.rays++;
-                bool more = true;
-                if (shade_core<AOV, SPH>(P, S, best)) {
-                    S.total = S.total + S.light;                    // main.wgsl:26
-                    S.sample++;
-                    more = S.sample < P.samples;
-                    if (more) new_path(P, C, S);                    // next sample, main.wgsl:36-41
+                // a lane comes here with a traced ray to shade, or (bounce == kFreshPixel) straight from FETCH with a
+                // new pixel whose first path starts here, where more lanes share the work than at the pixel boundary
+                const bool fresh = S.bounce == kFreshPixel;
+                bool more = true, next_sample = fresh;
+                if (!fresh) {
+                    tl.rays++;
+                    if (shade_core<AOV, SPH>(P, S, best)) {
+                        S.total = S.total + S.light;                // main.wgsl:26
+                        S.sample++;
+                        more = S.sample < P.samples;
+                        next_sample = more;
+                    }
                 }
+                if (next_sample) new_path(P, C, S);                 // next sample, main.wgsl:36-41
                 if (more) start_trace();
                 else phase = PH_FETCH;
             }
@@ -754,7 +761,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                         begin_pixel(P, C, S, x, y, lr, f);
                         have_pixel = true;
                         if (P.samples == 0) { S.total = v3(0.0f, 0.0f, 0.0f); }   // stays in FETCH: written out next round
-                            else { new_path(P, C, S); start_trace(); }
+                        else { S.bounce = kFreshPixel; phase = PH_SHADE; }          // first path starts in SHADE
                     }
                 }
                 w_next += take;
