@@ -103,7 +103,7 @@ __device__ __forceinline__ void intersect_tri(const DevTri *__restrict__ tris, u
     rt_v3 q = rt_cross_fma(tv, e1);
     float v = rt_dot_fma(d, q) * inv;
     float t = rt_dot_fma(e2, q) * inv;
-    bool front = cw ? (det < 0.0f) : (det > 0.0f);
+    bool front = (det > 0.0f) != cw;                  // cw ? det < 0 : det > 0 wherever det != 0, and det == 0 never hits
     bool ok = (det > 0.0f || det < 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > kTMin) &
               (!cull | front) & ((t < best.t) | ((t == best.t) & (gid < best.gid)));
     if (ok) {
