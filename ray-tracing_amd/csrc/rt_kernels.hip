@@ -39,6 +39,9 @@ constexpr int kBlock = 256;                  // 4 waves per workgroup
 #ifndef RT_NODE_EARLY_OUT
 #define RT_NODE_EARLY_OUT 2                  // leave the unrolled node steps when under 1/2 of the entering lanes remain (-1 %)
 #endif
+#ifndef RT_GUIDED_GRAIN
+#define RT_GUIDED_GRAIN 4u                     // chunks per claim while plenty of work is left
+#endif
 #ifndef RT_GUIDED_FACTOR
 #define RT_GUIDED_FACTOR 8u
 #endif
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 uint32_t grain = P.chunk;
                 if (lane == 0) {
                     const uint32_t seen = __hip_atomic_load(&P.queue->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (seen < total_slots && total_slots - seen > gridDim.x * (kBlock / 64u) * P.chunk * RT_GUIDED_FACTOR) grain = P.chunk * 4u;
+                    if (seen < total_slots && total_slots - seen > gridDim.x * (kBlock / 64u) * P.chunk * RT_GUIDED_FACTOR) grain = P.chunk * RT_GUIDED_GRAIN;
                     base = atomicAdd(&P.queue->head, grain);
                 }
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
