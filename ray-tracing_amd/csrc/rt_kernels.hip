@@ -49,7 +49,7 @@ constexpr int kBlock = 256;                  // 4 waves per workgroup
 #define RT_LEAF_REPS 2                       // triangle tests per scheduling decision
 #endif
 #ifndef RT_PHASED_WAVES
-#define RT_PHASED_WAVES 5                    // waves per SIMD the phased kernel is register-budgeted for
+#define RT_PHASED_WAVES 5                    // waves per SIMD the phased kernel must fit (96 VGPRs); it fits 6 (80) as built, see Makefile
 #endif
 constexpr float kTMin = 0.001f;              // main.wgsl:77
 constexpr float kTMax = 3.40282347e+38f;     // main.wgsl:77
