@@ -25,7 +25,7 @@
 #include "rt_pack.h"
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
-int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres);
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials);
 hipError_t rt_launch_capture(const float *accum, uint8_t *rgb, size_t n_pixels, hipStream_t stream);
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
@@ -460,6 +460,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
     }
     P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
     P.textures = ctx->d_textures; P.texels = ctx->d_texels; P.n_textures = ctx->n_textures;
+    P.n_materials = (uint32_t)(ctx->models.size() ? ctx->models.size() : 1);
     P.accum = ctx->d_accum;
     P.aov = ctx->opt_aov ? ctx->d_aov : nullptr;
     P.counters = ctx->d_counters;
@@ -499,9 +500,10 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
     if (ctx->opt_kernel != 1) {
         RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
         const bool ext = !ctx->spheres.empty() || ctx->n_textures > 0;
-        const int sel = (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
+        const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
+        const int sel = (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
         if (ctx->persistent_blocks == 0 || ctx->persistent_sel != sel) {
-            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext);
+            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm);
             ctx->persistent_sel = sel;
             if (ctx->tune[3] > 0 && ctx->cu_count > 0 && ctx->persistent_blocks > ctx->tune[3] * ctx->cu_count)
                 ctx->persistent_blocks = ctx->tune[3] * ctx->cu_count;       // developer knob 103: workgroups per CU

@@ -94,6 +94,10 @@ struct DevQueue {
     unsigned int pad[3];
 };
 
+// Material records (64 B each) the phased kernel copies into LDS at its start when the scene has no more than this
+// many: the L1 path is the busiest unit of that kernel and LDS is nearly idle.  Scenes with more read them from memory.
+#define RT_LDS_MATERIALS 16u
+
 struct RenderParams {
     const DevNode *nodes;
     const DevTri *tris;
@@ -101,7 +105,7 @@ struct RenderParams {
     const DevMaterial *materials;
     const DevTexture *textures;   // EXT builds only
     const uint32_t *texels;
-    uint32_t n_textures, pad_tex;
+    uint32_t n_textures, n_materials;   // n_materials: records behind `materials`
     float *accum;            // local rows x W x 4 f32
     uint32_t *aov;           // local rows x W x 2 u32, or null
     DevCounters *counters;

@@ -33,6 +33,7 @@
 namespace {
 
 constexpr int kBlock = 256;                  // 4 waves per workgroup
+__shared__ float4 g_lds_materials[RT_LDS_MATERIALS * 4u];   // LDSM instances of the phased kernel: the scene's material records
 #ifndef RT_NODE_REPS
 #define RT_NODE_REPS 3                       // node steps per scheduling decision
 #endif
@@ -346,7 +347,7 @@ __device__ __forceinline__ void finish_pixel(const RenderParams &P, const PixelS
 
 // Everything of sample()'s loop body after the trace (main.wgsl:46-69).
 // Returns true when the path ended (miss, or the bounce budget is spent).
-template <bool AOV, bool SPH>
+template <bool AOV, bool SPH, bool LDSM = false>
 __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S, const Hit &h_in) {
     Hit h = h_in;
     if (AOV && S.first_ray) {
@@ -383,8 +384,12 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
             h.front = rt_dot(S.dir, normal) < 0.0f;
             geometry = sh->pad0;
         }
-        const DevMaterial *mp = P.materials + geometry;             // models[geometry_index].material
-        const float4 m0 = ld4(&mp->tag), m1 = ld4(&mp->specular_probability), m2 = ld4(&mp->roughness);
+        // models[geometry_index].material, chunk k of its record: LDSM instances read the workgroup's LDS copy
+        auto mat_chunk = [&](uint32_t k) -> float4 {
+            if (LDSM) return g_lds_materials[geometry * 4u + k];
+            return ld4(reinterpret_cast<const float4 *>(P.materials + geometry) + k);
+        };
+        const float4 m0 = mat_chunk(0), m1 = mat_chunk(1), m2 = mat_chunk(2);
         const uint32_t tag = __float_as_uint(m0.x);
         if (tag == 0u) {                                            // main.wgsl:53-61
             // get_scattered_direction_metal, ray.wgsl:12-32
@@ -392,7 +397,9 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
             float smoothness = 1.0f - m2.x;
             rt_v3 scatter_normal = normal;
             rt_v3 diffuse_color = v3(m0.y, m0.z, m0.w);
-            if (SPH && (mp->normal_texture | mp->diffuse_texture) != 0u) {
+            const float4 m3 = SPH ? mat_chunk(3) : m0;               // texture ids: only instances with textures read them
+            const uint32_t mat_diffuse_texture = __float_as_uint(m3.y), mat_normal_texture = __float_as_uint(m3.z);
+            if (SPH && (mat_normal_texture | mat_diffuse_texture) != 0u) {
                 // trace.uv, main.wgsl:96 (spheres: uv = 0)
                 float tu = 0.0f, tv = 0.0f;
                 if (!(__float_as_uint(s3.w) & 0x80000000u)) {
@@ -401,11 +408,11 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
                     tu = u01.x * b0 + u01.z * b1 + u2.x * b2;
                     tv = u01.y * b0 + u01.w * b1 + u2.y * b2;
                 }
-                if (mp->normal_texture > 0u) {                              // ray.wgsl:17-20
-                    rt_v3 smp = sample_rgb(P, mp->normal_texture - 1u, tu, tv);
+                if (mat_normal_texture > 0u) {                              // ray.wgsl:17-20
+                    rt_v3 smp = sample_rgb(P, mat_normal_texture - 1u, tu, tv);
                     scatter_normal = tangent_space(normal, v3(smp.x * 2.0f - 1.0f, smp.y * 2.0f - 1.0f, smp.z * 2.0f - 1.0f));
                 }
-                if (mp->diffuse_texture > 0u) diffuse_color = sample_rgb(P, mp->diffuse_texture - 1u, tu, tv);   // ray.wgsl:26
+                if (mat_diffuse_texture > 0u) diffuse_color = sample_rgb(P, mat_diffuse_texture - 1u, tu, tv);   // ray.wgsl:26
             }
             rt_v3 diffuse = rand_cosine_hemisphere_vector(S.seed, scatter_normal);
             rt_v3 specular = rt_reflect(S.dir, scatter_normal);
@@ -418,7 +425,7 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
         } else if (tag == 1u) {                                     // main.wgsl:62-68
             // get_scattered_direction_dielectric, ray.wgsl:34-49
             rt_v3 n = rt_dot(normal, S.dir) < 0.0f ? normal : -normal;   // faceForward(N, N, dir)
-            const float ri_in = mp->refractive_index;
+            const float ri_in = mat_chunk(3).x;
             float ri = ri_in;
             if (h.front) ri = 1.0f / ri_in;
             float c = rt_dot(-S.dir, n);
@@ -571,10 +578,14 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_FETCH = 4, PH_DONE = 5 };
 constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel-frame that has not started its first path
 
-template <bool COUNT, bool AOV, bool SPH>
+template <bool COUNT, bool AOV, bool SPH, bool LDSM>
 __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
+    if (LDSM) {       // the host picks this instance when P.n_materials <= RT_LDS_MATERIALS
+        if (threadIdx.x < P.n_materials * 4u) g_lds_materials[threadIdx.x] = reinterpret_cast<const float4 *>(P.materials)[threadIdx.x];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t frame_slots = P.tiles_x * P.local_bands * 64u;
     const uint32_t total_slots = frame_slots * P.n_frames;    // work items: frame-major (host keeps this below 2^32)
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 bool more = true, next_sample = fresh;
                 if (!fresh) {
                     tl.rays++;
-                    if (shade_core<AOV, SPH>(P, S, best)) {
+                    if (shade_core<AOV, SPH, LDSM>(P, S, best)) {
                         S.total = S.total + S.light;                // main.wgsl:26
                         S.sample++;
                         more = S.sample < P.samples;
@@ -836,23 +847,28 @@ hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const Ren
 // Persistent grid size: the number of 256-thread workgroups of the given kernel
 // instance that are resident at once (register/LDS limited), so every wave
 // lives for the whole launch.
-int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres) {
+template <bool LDSM>
+static const void *phased_instance(int sel) {
+    switch (sel) {
+        case 0: return (const void *)rt_render_phased<false, false, false, LDSM>;
+        case 1: return (const void *)rt_render_phased<false, false, true, LDSM>;
+        case 2: return (const void *)rt_render_phased<false, true, false, LDSM>;
+        case 3: return (const void *)rt_render_phased<false, true, true, LDSM>;
+        case 4: return (const void *)rt_render_phased<true, false, false, LDSM>;
+        case 5: return (const void *)rt_render_phased<true, false, true, LDSM>;
+        case 6: return (const void *)rt_render_phased<true, true, false, LDSM>;
+        default: return (const void *)rt_render_phased<true, true, true, LDSM>;
+    }
+}
+
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
     const size_t lds = (size_t)stack_entries * kBlock * sizeof(uint32_t);
-    // the instances differ in register count, hence in how many workgroups fit
-    const void *fn = nullptr;
-    switch ((count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0)) {
-        case 0: fn = (const void *)rt_render_phased<false, false, false>; break;
-        case 1: fn = (const void *)rt_render_phased<false, false, true>; break;
-        case 2: fn = (const void *)rt_render_phased<false, true, false>; break;
-        case 3: fn = (const void *)rt_render_phased<false, true, true>; break;
-        case 4: fn = (const void *)rt_render_phased<true, false, false>; break;
-        case 5: fn = (const void *)rt_render_phased<true, false, true>; break;
-        case 6: fn = (const void *)rt_render_phased<true, true, false>; break;
-        default: fn = (const void *)rt_render_phased<true, true, true>; break;
-    }
+    // the instances differ in register count (and static LDS), hence in how many workgroups fit
+    const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
+    const void *fn = lds_materials ? phased_instance<true>(sel) : phased_instance<false>(sel);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu * prop.multiProcessorCount;
 }
@@ -862,7 +878,9 @@ template <bool COUNT, bool AOV, bool SPH>
 static hipError_t launch_variant(const RenderParams &P, int variant, dim3 tile_grid, dim3 persistent_grid, size_t lds, hipStream_t stream) {
     if (variant == 1) return launch(rt_render_tiles<COUNT, AOV, SPH>, tile_grid, lds, stream, P);
     if (variant == 0) return launch(rt_render_persistent<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
-    return launch(rt_render_phased<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
+    // LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS)
+    if (P.n_materials <= RT_LDS_MATERIALS) return launch(rt_render_phased<COUNT, AOV, SPH, true>, persistent_grid, lds, stream, P);
+    return launch(rt_render_phased<COUNT, AOV, SPH, false>, persistent_grid, lds, stream, P);
 }
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream) {

@@ -734,3 +734,49 @@ def test_degenerate_windows_and_frame_counts(rt):
             ctx.sync()
             assert ctx.accum_download().shape == (h, w, 4) and ctx.capture_rgb8().shape == (h, w, 3)
             assert ctx.stats().pixel_frames == 4 * w * h
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_geo", [16, 17, 40])
+def test_material_records_in_lds_or_memory(rt, oracle_mod, obj_loader, n_geo):
+    """The default kernel keeps up to 16 material records (RT_LDS_MATERIALS) in LDS and reads them from memory
+    beyond that: both instances against the oracle's brute force on a scene of n_geo small soups, each with its own
+    metal or dielectric material."""
+    rng = np.random.default_rng(100 + n_geo)
+    n = 60
+    V = np.zeros(3 * n * n_geo, obj_loader.VERTEX_DTYPE)
+    P = np.zeros(n_geo, obj_loader.PRIMITIVE_DTYPE)
+    M = np.zeros(n_geo, obj_loader.MODEL_DTYPE)
+    for g in range(n_geo):
+        s = _soup(obj_loader, rng, n, np.array([(g % 8) - 3.5, (g // 8) - 2.0, 0.0]), 0.45, 0.35)
+        V[3 * n * g:3 * n * (g + 1)] = s.vertices
+        P[g] = (3 * n * g, 3 * n, 3 * n * g, 3 * n, g)
+        M[g] = s.models[0]
+        M[g]["tag"] = 1 if g % 5 == 4 else 0
+        M[g]["diffuse_color"] = rng.random(3)
+        M[g]["specular_color"] = rng.random(3)
+        M[g]["specular_probability"] = rng.random()
+        M[g]["roughness"] = rng.random()
+        M[g]["emission_color"] = rng.random(3)
+        M[g]["emission_strength"] = 2.0 * (g % 3 == 0)
+        M[g]["refractive_index"] = 1.0 + rng.random()
+        M[g]["vertex_start"] = 3 * n * g
+        M[g]["index_start"] = 3 * n * g
+    I = np.tile(np.arange(3 * n, dtype=np.uint32), n_geo)          # indices are object-local (main.wgsl:89-91)
+    scene = obj_loader.Scene(V, I, P, M)
+    w, h, kw = 72, 44, dict(max_bounces=5, samples=2)
+    pos, yaw = (0.0, 0.0, -5.0), np.pi / 2
+    want, want_hits, cnt = oracle_mod.OracleScene(scene, build_bvh=False).render(oracle_mod.make_uniform(w, h, pos, yaw, **kw), mode=0, want_hits=True)
+    assert len(np.unique(want_hits[..., 0])) > n_geo // 2               # most materials are on screen
+    with rt.Context(0) as ctx:
+        ctx.scene_upload(V, I, P, M)
+        ctx.set_option(rt.RT_OPT_AOV, 1)
+        ctx.accum_resize(w, h)
+        ctx.dispatch(rt.make_uniform(w, h, pos, yaw, **kw))
+        assert ctx.stats().rays == cnt.rays
+        assert np.array_equal(ctx.aov_download(), want_hits)
+        assert_images_identical(ctx.accum_download(), want, f"{n_geo} materials")
+        # a later upload with more / fewer materials switches instance
+        ctx.set_option(rt.RT_OPT_AOV, 0)
+        ctx.dispatch(rt.make_uniform(w, h, pos, yaw, **kw))
+        assert_images_identical(ctx.accum_download(), want, f"{n_geo} materials, no AOV")
