@@ -55,6 +55,7 @@ RT_OPT_FRONT_FACE_CW = 4
 RT_OPT_REFIT = 5
 RT_OPT_NODE_STRIDE = 6
 RT_OPT_FRAME_PIPELINE = 7
+RT_OPT_NODE_FORMAT = 8
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_option",

@@ -25,11 +25,11 @@
 #include "rt_pack.h"
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
-int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials);
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, bool q8);
 hipError_t rt_launch_capture(const float *accum, uint8_t *rgb, size_t n_pixels, hipStream_t stream);
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
-                           RtRefitBox *root_out, hipStream_t stream);
+                           RtRefitBox *root_out, bool q8, hipStream_t stream);
 
 namespace {
 
@@ -116,6 +116,8 @@ struct rt_context {
     bool opt_count = false, opt_aov = false, opt_cw = false;
     int opt_refit = 2;               // RT_OPT_REFIT: 0 rebuild, 1 host refit, 2 device refit
     int opt_node_stride = 0;
+    int opt_node_format = 0;         // RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte nodes, 2 32-byte q8 nodes
+    bool node_q8 = false;            // format of the nodes on the device
     int opt_kernel = 2;
     int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE, workgroups per CU (0 = all that fit), FETCH weight, -, builder max_leaf, bins
     float4 *d_stage = nullptr;       // per-frame sample sums of a multi-frame launch (lazy, grows)
@@ -152,6 +154,7 @@ uint64_t local_rows_for(uint32_t h, uint32_t shard_index, uint32_t shard_count) 
 struct Repacked {
     std::vector<DevNode> nodes;      // node i; uploaded at 16-byte chunk i * node_stride
     uint32_t node_stride = RT_NODE_CHUNKS;
+    bool q8 = false;                 // 32-byte records (rt_pack.h), node_stride 2
     std::vector<int32_t> parent;     // node -> parent * 2 + child slot (device refit)
     bool refit_sources_agree = true; // shading-record corners == BLAS corners (see repack)
     std::vector<DevTri> tris;
@@ -164,7 +167,12 @@ inline float pad_lo(float v) { return rt_pad_lo(v); }
 inline float pad_hi(float v) { return rt_pad_hi(v); }
 
 // Both children of one node: padded boxes → lower corner + outward-rounded f16 offsets (rt_pack.h).
-void set_children(DevNode &n, const rt_host::Aabb &box0, int32_t ref0, const rt_host::Aabb &box1, int32_t ref1) {
+void set_children(DevNode &n, const rt_host::Aabb &box0, int32_t ref0, const rt_host::Aabb &box1, int32_t ref1, bool q8) {
+    if (q8) {
+        memset(&n, 0, sizeof n);
+        rt_pack_children_q8(n, box0.lo, box0.hi, box1.lo, box1.hi, ref0, ref1);
+        return;
+    }
     rt_pack_children(n, box0.lo, box0.hi, box1.lo, box1.hi);
     n.ref0 = ref0; n.ref1 = ref1;
     n.pad = 0;
@@ -249,7 +257,7 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         memset(&out.nodes[0], 0, sizeof(DevNode));
         rt_host::Aabb box = root.box;
         if (n_tris == 0) for (int k = 0; k < 3; k++) { box.lo[k] = 0.0f; box.hi[k] = 0.0f; }
-        set_children(out.nodes[0], box, dev_leaf_ref(root.left, n_tris ? root.count : 0), box, dev_leaf_ref(0, 0));
+        set_children(out.nodes[0], box, dev_leaf_ref(root.left, n_tris ? root.count : 0), box, dev_leaf_ref(0, 0), out.q8);
         out.stack_entries = 2;
         return;
     }
@@ -273,7 +281,7 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         uint32_t d0 = 0, d1 = 0;
         if (c0.count) r0 = leaf_ref(c0); else { d0 = next++; r0 = (int32_t)(d0 * out.node_stride); out.parent[d0] = (int32_t)(it.dst * 2u); }
         if (c1.count) r1 = leaf_ref(c1); else { d1 = next++; r1 = (int32_t)(d1 * out.node_stride); out.parent[d1] = (int32_t)(it.dst * 2u + 1u); }
-        set_children(d, c0.box, r0, c1.box, r1);
+        set_children(d, c0.box, r0, c1.box, r1, out.q8);
         if (!c1.count) todo.push_back({n.left + 1, d1});
         if (!c0.count) todo.push_back({n.left, d0});
     }
@@ -358,8 +366,36 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     // Node stride: 48 B (default) packs the tree tightest; 64 B keeps every node inside one 64-B memory sector.
     // Measured: 48 B is 1.5 % faster on C3 (cache-resident), no difference on C4 (2 GB of records).
     rp.node_stride = ctx->opt_node_stride ? (uint32_t)ctx->opt_node_stride : (uint32_t)RT_NODE_CHUNKS;
+    {
+        // Node format (rt_pack.h): 32-byte q8 records when the references and the extents fit AND the nodes are too
+        // many to stay in the caches (measured: C4, 244 MB of 48-byte nodes, 8 % faster; C3, 0.26 MB, 2 % slower)
+        float ext = 0.0f;
+        bool finite = true;
+        for (int k = 0; k < 3 && n_prims; k++) {
+            const float d = bvh.nodes[0].box.hi[k] - bvh.nodes[0].box.lo[k];
+            if (!(d <= 3.0e38f)) finite = false;
+            ext = fmaxf(ext, d);
+        }
+        const bool fits = finite && ext <= RT_Q8_MAX_EXTENT && bvh.nodes.size() * 2ull < RT_Q8_MAX_REF && ((n_prims << 3) | 7ull) < RT_Q8_MAX_REF;
+        rp.q8 = fits && (ctx->opt_node_format == 2 || (ctx->opt_node_format == 0 && bvh.nodes.size() * sizeof(DevNode) / 2 >= (16ull << 20)));
+        if (rp.q8) rp.node_stride = 2;
+    }
     repack(bvh, corners, ids, *ctx, rp);
     ctx->build_seconds = bvh.build_seconds;
+    // q8 nodes keep their scale in spare reference bits: every stored reference must decode to something inside the arrays
+    for (size_t i = 0; rp.q8 && i < rp.nodes.size(); i++) {
+        const int32_t r[2] = {rt_q8_ref_load(rp.nodes[i].ref0), rt_q8_ref_load(rp.nodes[i].ref1)};
+        for (int c = 0; c < 2; c++) {
+            if (r[c] >= 0) {
+                if ((uint32_t)r[c] % rp.node_stride != 0u || (uint64_t)r[c] / rp.node_stride >= rp.nodes.size() || (uint32_t)r[c] >= (1u << 27))
+                    return fail(RT_ERR_INVALID_ARGUMENT, "q8 node %zu: inner reference %d out of range", i, r[c]);
+            } else {
+                const uint32_t enc = (uint32_t)~r[c];
+                if (enc >= (1u << 27) || (uint64_t)(enc >> 3) + (enc & 7u) > rp.tris.size())
+                    return fail(RT_ERR_INVALID_ARGUMENT, "q8 node %zu: leaf reference %u out of range", i, enc);
+            }
+        }
+    }
 
     std::vector<DevMaterial> mats;
     convert_materials(*ctx, mats);
@@ -376,11 +412,13 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
         RT_HIP(hipMemcpy(ctx->d_nodes, rp.nodes.data(), node_bytes, hipMemcpyHostToDevice));
     } else {
         RT_HIP(hipMemset(ctx->d_nodes, 0, node_bytes));
-        RT_HIP(hipMemcpy2D(ctx->d_nodes, (size_t)rp.node_stride * 16u, rp.nodes.data(), sizeof(DevNode), sizeof(DevNode), rp.nodes.size(),
+        const size_t row = rp.node_stride * 16u < sizeof(DevNode) ? rp.node_stride * 16u : sizeof(DevNode);
+        RT_HIP(hipMemcpy2D(ctx->d_nodes, (size_t)rp.node_stride * 16u, rp.nodes.data(), sizeof(DevNode), row, rp.nodes.size(),
                            hipMemcpyHostToDevice));
     }
     ctx->node_bytes = node_bytes;
     ctx->node_stride = rp.node_stride;
+    ctx->node_q8 = rp.q8;
     dev_free(ctx->d_parent); dev_free(ctx->d_arrived); dev_free(ctx->d_cbox); dev_free(ctx->d_tribox); dev_free(ctx->d_root); dev_free(ctx->d_xform);
     if (ctx->opt_refit == 2 && rp.refit_sources_agree && rp.parent.size() == rp.nodes.size() && rp.nodes.size() > 1) {
         const size_t nn = rp.nodes.size();
@@ -458,6 +496,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
         P.stage = ctx->d_stage;
         P.stage_stride = (uint64_t)P.local_rows * ctx->width;
     }
+    P.node_q8 = ctx->node_q8 ? 1u : 0u;
     P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
     P.textures = ctx->d_textures; P.texels = ctx->d_texels; P.n_textures = ctx->n_textures;
     P.n_materials = (uint32_t)(ctx->models.size() ? ctx->models.size() : 1);
@@ -501,9 +540,9 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
         RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
         const bool ext = !ctx->spheres.empty() || ctx->n_textures > 0;
         const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
-        const int sel = (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
+        const int sel = (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
         if (ctx->persistent_blocks == 0 || ctx->persistent_sel != sel) {
-            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm);
+            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm, ctx->node_q8);
             ctx->persistent_sel = sel;
             if (ctx->tune[3] > 0 && ctx->cu_count > 0 && ctx->persistent_blocks > ctx->tune[3] * ctx->cu_count)
                 ctx->persistent_blocks = ctx->tune[3] * ctx->cu_count;       // developer knob 103: workgroups per CU
@@ -577,7 +616,7 @@ int device_refit(rt_context *ctx) {
         xform = ctx->d_xform;
     }
     RT_HIP(rt_launch_refit(ctx->d_tris, ctx->d_shade, xform, ctx->d_tribox, ctx->n_tris, reinterpret_cast<float4 *>(ctx->d_nodes), ctx->node_stride,
-                           ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, ctx->stream));
+                           ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, ctx->node_q8, ctx->stream));
     RtRefitBox root;
     RT_HIP(hipMemcpyAsync(&root, ctx->d_root, sizeof root, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));                   // also keeps `mats` / `resolved` alive long enough
@@ -587,6 +626,13 @@ int device_refit(rt_context *ctx) {
     }
     ctx->refits++;
     ctx->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (ctx->node_q8) {
+        // the moved scene may have outgrown what 8-bit offsets can span (their outward rounding saturates there):
+        // rebuild on the host, which chooses the node format again
+        float ext = 0.0f;
+        for (int k = 0; k < 3; k++) ext = fmaxf(ext, root.hi[k] - root.lo[k]);
+        if (!(ext <= RT_Q8_MAX_EXTENT)) return build_and_upload(ctx, true);
+    }
     return RT_OK;
 }
 
@@ -659,6 +705,10 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             ctx->opt_refit = (int)value;
             return RT_OK;
         case RT_OPT_FRAME_PIPELINE: ctx->opt_pipeline = value != 0; return RT_OK;
+        case RT_OPT_NODE_FORMAT:
+            if (value < 0 || value > 2) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_FORMAT: 0 (by size), 1 (48-byte) or 2 (32-byte)");
+            ctx->opt_node_format = (int)value;
+            return RT_OK;
         case RT_OPT_NODE_STRIDE:
             if (value != 0 && value != 3 && value != 4) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_STRIDE: 0 (auto), 3 or 4");
             ctx->opt_node_stride = value;

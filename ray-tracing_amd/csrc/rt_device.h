@@ -105,6 +105,7 @@ struct RenderParams {
     const DevMaterial *materials;
     const DevTexture *textures;   // EXT builds only
     const uint32_t *texels;
+    uint32_t node_q8, pad_q8;            // 1: nodes are 32-byte records with 8-bit plane offsets (rt_pack.h), stride 2 chunks
     uint32_t n_textures, n_materials;   // n_materials: records behind `materials`
     float *accum;            // local rows x W x 4 f32
     uint32_t *aov;           // local rows x W x 2 u32, or null

@@ -29,6 +29,7 @@
 
 #include "rt_device.h"
 #include "rt_math.h"
+#include "rt_pack.h"
 
 namespace {
 
@@ -155,19 +156,38 @@ __device__ __forceinline__ Slab make_slab(const RenderParams &P, rt_v3 o, rt_v3 
     return s;
 }
 // both children of one node: entry distances n0/n1, hit flags, references
-__device__ __forceinline__ void test_node(const float4 *n, const Slab &sl, float tbest, bool &h0, bool &h1, float &n0,
+__device__ __forceinline__ void test_node(const float4 *n, const Slab &sl, float tbest, bool q8, bool &h0, bool &h1, float &n0,
                                           float &n1, int2 &refs) {
     const float4 a = ld4(n);
-    const uint4 b = ld4u(n + 1), c = ld4u(n + 2);
-    refs.x = __float_as_int(a.w);
-    refs.y = (int32_t)b.w;
+    const uint4 b = ld4u(n + 1);
     const float bx = fmaf(a.x, sl.ix, sl.ox), by = fmaf(a.y, sl.iy, sl.oy), bz = fmaf(a.z, sl.iz, sl.oz);
-    const float t0x = fmaf(lo16(b.x), sl.ix, bx), t1x = fmaf(hi16(b.x), sl.ix, bx);
-    const float t0y = fmaf(lo16(b.y), sl.iy, by), t1y = fmaf(hi16(b.y), sl.iy, by);
-    const float t0z = fmaf(lo16(b.z), sl.iz, bz), t1z = fmaf(hi16(b.z), sl.iz, bz);
-    const float s0x = fmaf(lo16(c.x), sl.ix, bx), s1x = fmaf(hi16(c.x), sl.ix, bx);
-    const float s0y = fmaf(lo16(c.y), sl.iy, by), s1y = fmaf(hi16(c.y), sl.iy, by);
-    const float s0z = fmaf(lo16(c.z), sl.iz, bz), s1z = fmaf(hi16(c.z), sl.iz, bz);
+    float t0x, t1x, t0y, t1y, t0z, t1z, s0x, s1x, s0y, s1y, s0z, s1z;
+    if (q8) {
+        // two-load node (rt_pack.h): 8-bit plane offsets in units of scale = 2^(e - 20), per axis [c0.lo, c1.lo, c0.hi, c1.hi]
+        const uint32_t r0 = __float_as_uint(a.w), r1 = b.w;
+        const uint32_t e5 = ((r0 >> 27) & 15u) | ((r1 >> 23) & 16u);
+        const float scale = __uint_as_float((e5 + (127u - RT_Q8_EXP_BIAS)) << 23);
+        refs.x = rt_q8_ref_load((int32_t)r0);
+        refs.y = rt_q8_ref_load((int32_t)r1);
+        const float sx = scale * sl.ix, sy = scale * sl.iy, sz = scale * sl.iz;
+        auto ub = [](uint32_t v, int k) { return (float)((v >> (8 * k)) & 255u); };
+        t0x = fmaf(ub(b.x, 0), sx, bx); t1x = fmaf(ub(b.x, 2), sx, bx);
+        t0y = fmaf(ub(b.y, 0), sy, by); t1y = fmaf(ub(b.y, 2), sy, by);
+        t0z = fmaf(ub(b.z, 0), sz, bz); t1z = fmaf(ub(b.z, 2), sz, bz);
+        s0x = fmaf(ub(b.x, 1), sx, bx); s1x = fmaf(ub(b.x, 3), sx, bx);
+        s0y = fmaf(ub(b.y, 1), sy, by); s1y = fmaf(ub(b.y, 3), sy, by);
+        s0z = fmaf(ub(b.z, 1), sz, bz); s1z = fmaf(ub(b.z, 3), sz, bz);
+    } else {
+        const uint4 c = ld4u(n + 2);
+        refs.x = __float_as_int(a.w);
+        refs.y = (int32_t)b.w;
+        t0x = fmaf(lo16(b.x), sl.ix, bx); t1x = fmaf(hi16(b.x), sl.ix, bx);
+        t0y = fmaf(lo16(b.y), sl.iy, by); t1y = fmaf(hi16(b.y), sl.iy, by);
+        t0z = fmaf(lo16(b.z), sl.iz, bz); t1z = fmaf(hi16(b.z), sl.iz, bz);
+        s0x = fmaf(lo16(c.x), sl.ix, bx); s1x = fmaf(hi16(c.x), sl.ix, bx);
+        s0y = fmaf(lo16(c.y), sl.iy, by); s1y = fmaf(hi16(c.y), sl.iy, by);
+        s0z = fmaf(lo16(c.z), sl.iz, bz); s1z = fmaf(hi16(c.z), sl.iz, bz);
+    }
     n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
     const float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tbest));
     n1 = fmaxf(fmaxf(fminf(s0x, s1x), fminf(s0y, s1y)), fmaxf(fminf(s0z, s1z), kTMin));
@@ -195,7 +215,7 @@ __device__ __forceinline__ Hit trace(const RenderParams &P, uint32_t *__restrict
             bool h0, h1;
             float n0, n1;
             int2 refs;
-            test_node(nodes + cur, sl, best.t, h0, h1, n0, n1, refs);
+            test_node(nodes + cur, sl, best.t, P.node_q8 != 0u, h0, h1, n0, n1, refs);
             if (h0 && h1) {
                 bool swap = n1 < n0;
                 int32_t nearc = swap ? refs.y : refs.x, farc = swap ? refs.x : refs.y;
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_FETCH = 4, PH_DONE = 5 };
 constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel-frame that has not started its first path
 
-template <bool COUNT, bool AOV, bool SPH, bool LDSM>
+template <bool COUNT, bool AOV, bool SPH, bool LDSM, bool Q8>
 __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -651,21 +671,45 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 if (phase == PH_NODE) {
                     if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
                     const float4 *n = nodes + cur;
-                    const float4 a = ld4(n);
-                    const uint4 b = ld4u(n + 1), c = ld4u(n + 2);
-                    const int2 refs = make_int2(__float_as_int(a.w), (int32_t)b.w);
-                    const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
-                    // rotate each (hi << 16 | lo) offset pair by 0 or 16 bits (bits 4:0 of the stuffed inverse,
-                    // see start_trace): the low half becomes the plane the ray ENTERS through, no min/max needed
+                    float n0, n1, f0, f1;
+                    int2 refs;
+                    // rotate amounts: bits 4:0 of the stuffed inverse (see start_trace), 16 for a negative direction
                     const uint32_t rx = __float_as_uint(ix), ry = __float_as_uint(iy), rz = __float_as_uint(iz);
-                    const uint32_t p0x = __builtin_amdgcn_alignbit(b.x, b.x, rx), p0y = __builtin_amdgcn_alignbit(b.y, b.y, ry),
-                                   p0z = __builtin_amdgcn_alignbit(b.z, b.z, rz);
-                    const uint32_t p1x = __builtin_amdgcn_alignbit(c.x, c.x, rx), p1y = __builtin_amdgcn_alignbit(c.y, c.y, ry),
-                                   p1z = __builtin_amdgcn_alignbit(c.z, c.z, rz);
-                    const float n0 = fmaxf(fmaxf(fmaf(lo16(p0x), ix, bx), fmaf(lo16(p0y), iy, by)), fmaxf(fmaf(lo16(p0z), iz, bz), kTMin));
-                    const float f0 = fminf(fminf(fmaf(hi16(p0x), ix, bx), fmaf(hi16(p0y), iy, by)), fminf(fmaf(hi16(p0z), iz, bz), best.t));
-                    const float n1 = fmaxf(fmaxf(fmaf(lo16(p1x), ix, bx), fmaf(lo16(p1y), iy, by)), fmaxf(fmaf(lo16(p1z), iz, bz), kTMin));
-                    const float f1 = fminf(fminf(fmaf(hi16(p1x), ix, bx), fmaf(hi16(p1y), iy, by)), fminf(fmaf(hi16(p1z), iz, bz), best.t));
+                    if (Q8) {
+                        // 32-byte node (rt_pack.h): two loads; per axis one dword [c0.lo, c1.lo, c0.hi, c1.hi] of 8-bit
+                        // offsets in units of scale = 2^(e - 20); rotating it by 0 or 16 bits puts the planes the ray
+                        // ENTERS through into bytes 0 and 1
+                        const float4 a = ld4(n);
+                        const uint4 b = ld4u(n + 1);
+                        const uint32_t r0 = __float_as_uint(a.w), r1 = b.w;
+                        const uint32_t e5 = ((r0 >> 27) & 15u) | ((r1 >> 23) & 16u);
+                        const float scale = __uint_as_float((e5 + (127u - RT_Q8_EXP_BIAS)) << 23);
+                        refs = make_int2(rt_q8_ref_load((int32_t)r0), rt_q8_ref_load((int32_t)r1));
+                        const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
+                        const float sx = scale * ix, sy = scale * iy, sz = scale * iz;
+                        const uint32_t px = __builtin_amdgcn_alignbit(b.x, b.x, rx), py = __builtin_amdgcn_alignbit(b.y, b.y, ry),
+                                       pz = __builtin_amdgcn_alignbit(b.z, b.z, rz);
+                        auto ub = [](uint32_t v, int k) { return (float)((v >> (8 * k)) & 255u); };
+                        n0 = fmaxf(fmaxf(fmaf(ub(px, 0), sx, bx), fmaf(ub(py, 0), sy, by)), fmaxf(fmaf(ub(pz, 0), sz, bz), kTMin));
+                        n1 = fmaxf(fmaxf(fmaf(ub(px, 1), sx, bx), fmaf(ub(py, 1), sy, by)), fmaxf(fmaf(ub(pz, 1), sz, bz), kTMin));
+                        f0 = fminf(fminf(fmaf(ub(px, 2), sx, bx), fmaf(ub(py, 2), sy, by)), fminf(fmaf(ub(pz, 2), sz, bz), best.t));
+                        f1 = fminf(fminf(fmaf(ub(px, 3), sx, bx), fmaf(ub(py, 3), sy, by)), fminf(fmaf(ub(pz, 3), sz, bz), best.t));
+                    } else {
+                        // 48-byte node: three loads; rotating each (hi << 16 | lo) f16 offset pair by 0 or 16 bits makes the
+                        // low half the plane the ray ENTERS through, no min/max needed
+                        const float4 a = ld4(n);
+                        const uint4 b = ld4u(n + 1), c = ld4u(n + 2);
+                        refs = make_int2(__float_as_int(a.w), (int32_t)b.w);
+                        const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
+                        const uint32_t p0x = __builtin_amdgcn_alignbit(b.x, b.x, rx), p0y = __builtin_amdgcn_alignbit(b.y, b.y, ry),
+                                       p0z = __builtin_amdgcn_alignbit(b.z, b.z, rz);
+                        const uint32_t p1x = __builtin_amdgcn_alignbit(c.x, c.x, rx), p1y = __builtin_amdgcn_alignbit(c.y, c.y, ry),
+                                       p1z = __builtin_amdgcn_alignbit(c.z, c.z, rz);
+                        n0 = fmaxf(fmaxf(fmaf(lo16(p0x), ix, bx), fmaf(lo16(p0y), iy, by)), fmaxf(fmaf(lo16(p0z), iz, bz), kTMin));
+                        f0 = fminf(fminf(fmaf(hi16(p0x), ix, bx), fmaf(hi16(p0y), iy, by)), fminf(fmaf(hi16(p0z), iz, bz), best.t));
+                        n1 = fmaxf(fmaxf(fmaf(lo16(p1x), ix, bx), fmaf(lo16(p1y), iy, by)), fmaxf(fmaf(lo16(p1z), iz, bz), kTMin));
+                        f1 = fminf(fminf(fmaf(hi16(p1x), ix, bx), fmaf(hi16(p1y), iy, by)), fminf(fmaf(hi16(p1z), iz, bz), best.t));
+                    }
                     const bool h0 = n0 <= fmaf(f0, kFarSlack, eps);
                     const bool h1 = n1 <= fmaf(f1, kFarSlack, eps);
                     // next reference: the nearer hit child; the other one (if hit) is pushed
@@ -847,28 +891,29 @@ hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const Ren
 // Persistent grid size: the number of 256-thread workgroups of the given kernel
 // instance that are resident at once (register/LDS limited), so every wave
 // lives for the whole launch.
-template <bool LDSM>
+template <bool LDSM, bool Q8>
 static const void *phased_instance(int sel) {
     switch (sel) {
-        case 0: return (const void *)rt_render_phased<false, false, false, LDSM>;
-        case 1: return (const void *)rt_render_phased<false, false, true, LDSM>;
-        case 2: return (const void *)rt_render_phased<false, true, false, LDSM>;
-        case 3: return (const void *)rt_render_phased<false, true, true, LDSM>;
-        case 4: return (const void *)rt_render_phased<true, false, false, LDSM>;
-        case 5: return (const void *)rt_render_phased<true, false, true, LDSM>;
-        case 6: return (const void *)rt_render_phased<true, true, false, LDSM>;
-        default: return (const void *)rt_render_phased<true, true, true, LDSM>;
+        case 0: return (const void *)rt_render_phased<false, false, false, LDSM, Q8>;
+        case 1: return (const void *)rt_render_phased<false, false, true, LDSM, Q8>;
+        case 2: return (const void *)rt_render_phased<false, true, false, LDSM, Q8>;
+        case 3: return (const void *)rt_render_phased<false, true, true, LDSM, Q8>;
+        case 4: return (const void *)rt_render_phased<true, false, false, LDSM, Q8>;
+        case 5: return (const void *)rt_render_phased<true, false, true, LDSM, Q8>;
+        case 6: return (const void *)rt_render_phased<true, true, false, LDSM, Q8>;
+        default: return (const void *)rt_render_phased<true, true, true, LDSM, Q8>;
     }
 }
 
-int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials) {
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, bool q8) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
     const size_t lds = (size_t)stack_entries * kBlock * sizeof(uint32_t);
     // the instances differ in register count (and static LDS), hence in how many workgroups fit
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
-    const void *fn = lds_materials ? phased_instance<true>(sel) : phased_instance<false>(sel);
+    const void *fn = lds_materials ? (q8 ? phased_instance<true, true>(sel) : phased_instance<true, false>(sel))
+                                   : (q8 ? phased_instance<false, true>(sel) : phased_instance<false, false>(sel));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu * prop.multiProcessorCount;
 }
@@ -878,9 +923,12 @@ template <bool COUNT, bool AOV, bool SPH>
 static hipError_t launch_variant(const RenderParams &P, int variant, dim3 tile_grid, dim3 persistent_grid, size_t lds, hipStream_t stream) {
     if (variant == 1) return launch(rt_render_tiles<COUNT, AOV, SPH>, tile_grid, lds, stream, P);
     if (variant == 0) return launch(rt_render_persistent<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
-    // LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS)
-    if (P.n_materials <= RT_LDS_MATERIALS) return launch(rt_render_phased<COUNT, AOV, SPH, true>, persistent_grid, lds, stream, P);
-    return launch(rt_render_phased<COUNT, AOV, SPH, false>, persistent_grid, lds, stream, P);
+    // LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS); Q8: 32-byte nodes
+    const bool ldsm = P.n_materials <= RT_LDS_MATERIALS, q8 = P.node_q8 != 0u;
+    if (ldsm && q8) return launch(rt_render_phased<COUNT, AOV, SPH, true, true>, persistent_grid, lds, stream, P);
+    if (ldsm) return launch(rt_render_phased<COUNT, AOV, SPH, true, false>, persistent_grid, lds, stream, P);
+    if (q8) return launch(rt_render_phased<COUNT, AOV, SPH, false, true>, persistent_grid, lds, stream, P);
+    return launch(rt_render_phased<COUNT, AOV, SPH, false, false>, persistent_grid, lds, stream, P);
 }
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream) {

@@ -54,6 +54,49 @@ RT_HD void rt_pack_children(DevNode &n, const float *blo0, const float *bhi0, co
     n.c1x = c1[0]; n.c1y = c1[1]; n.c1z = c1[2];
 }
 
+// Two-load node ("q8", RT_OPT_NODE_FORMAT): a 32-byte record = the first 32 bytes of a DevNode: the lower corner,
+// per axis one dword of four 8-bit plane offsets [c0.lo, c1.lo, c0.hi, c1.hi] in units of scale = 2^(e - 20), and the
+// two references with the 5-bit e in their spare bits 30..27 (ref0: e & 15, ref1: e >> 4).  Offsets are rounded
+// outward.  Needs references below 2^27 and node extents up to 255 * 2^11 (RT_Q8_MAX_EXTENT); the host falls back
+// to 48-byte nodes otherwise.  A third less node memory: 8 % faster where node fetches miss the caches (config C4),
+// 2 % slower where they do not (C3: the decode costs ~20 VALU instructions more per visit), hence chosen by size.
+#define RT_Q8_MAX_EXTENT 262144.0f
+#define RT_Q8_MAX_REF (1u << 27)
+#define RT_Q8_EXP_BIAS 20
+RT_HD int32_t rt_q8_ref_store(int32_t ref, uint32_t ebits) { return (int32_t)(((uint32_t)ref & 0x87FFFFFFu) | (ebits << 27)); }
+RT_HD int32_t rt_q8_ref_load(int32_t stored) {
+    const uint32_t p = (uint32_t)stored & 0x87FFFFFFu;
+    return (int32_t)(p | ((uint32_t)((int32_t)p >> 31) & 0x78000000u));
+}
+RT_HD void rt_pack_children_q8(DevNode &n, const float *blo0, const float *bhi0, const float *blo1, const float *bhi1, int32_t ref0, int32_t ref1) {
+    float lo0[3], hi0[3], lo1[3], hi1[3], lo[3];
+    double ext = 0.0;
+    for (int k = 0; k < 3; k++) {
+        lo0[k] = rt_pad_lo(blo0[k]); hi0[k] = rt_pad_hi(bhi0[k]);
+        lo1[k] = rt_pad_lo(blo1[k]); hi1[k] = rt_pad_hi(bhi1[k]);
+        lo[k] = lo0[k] < lo1[k] ? lo0[k] : lo1[k];
+        const float hi = hi0[k] > hi1[k] ? hi0[k] : hi1[k];
+        const double d = (double)hi - (double)lo[k];
+        if (d > ext) ext = d;
+    }
+    int e = 0;
+    while (e < 31 && 255.0 * ldexp(1.0, e - RT_Q8_EXP_BIAS) < ext) e++;
+    const double inv_scale = ldexp(1.0, RT_Q8_EXP_BIAS - e);
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) {
+        const double l0 = floor(((double)lo0[k] - (double)lo[k]) * inv_scale), h0 = ceil(((double)hi0[k] - (double)lo[k]) * inv_scale);
+        const double l1 = floor(((double)lo1[k] - (double)lo[k]) * inv_scale), h1 = ceil(((double)hi1[k] - (double)lo[k]) * inv_scale);
+        // empty children (lo = +inf, hi = -inf) and NaNs end as lo 255 / hi 0: never entered
+        const uint32_t ql0 = l0 >= 0.0 && l0 <= 255.0 ? (uint32_t)l0 : (l0 < 0.0 ? 0u : 255u), qh0 = h0 >= 0.0 && h0 <= 255.0 ? (uint32_t)h0 : (h0 > 255.0 ? 255u : 0u);
+        const uint32_t ql1 = l1 >= 0.0 && l1 <= 255.0 ? (uint32_t)l1 : (l1 < 0.0 ? 0u : 255u), qh1 = h1 >= 0.0 && h1 <= 255.0 ? (uint32_t)h1 : (h1 > 255.0 ? 255u : 0u);
+        q[k] = ql0 | (ql1 << 8) | (qh0 << 16) | (qh1 << 24);
+    }
+    n.lox = lo[0]; n.loy = lo[1]; n.loz = lo[2];
+    n.c0x = q[0]; n.c0y = q[1]; n.c0z = q[2];
+    n.ref0 = rt_q8_ref_store(ref0, (uint32_t)e & 15u);
+    n.ref1 = rt_q8_ref_store(ref1, (uint32_t)e >> 4);
+}
+
 // geometry transform of one corner, the host's expression (host/bvh_builder.cpp gather_triangles): every
 // product and sum rounds once (this file is compiled with -ffp-contract=off on both sides)
 RT_HD void rt_transform_point(const float *m, const float *v, float *dst) {

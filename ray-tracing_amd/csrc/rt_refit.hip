@@ -55,11 +55,12 @@ __global__ __launch_bounds__(256) void rt_refit_tris(DevTri *__restrict__ tris, 
 
 __global__ __launch_bounds__(256) void rt_refit_nodes(float4 *__restrict__ chunks, uint32_t stride, const int32_t *__restrict__ parent,
                                                       unsigned int *__restrict__ arrived, RtRefitBox *cbox, const RtRefitBox *__restrict__ tribox,
-                                                      uint32_t n_nodes, uint64_t n_slots, RtRefitBox *root_out) {
+                                                      uint32_t n_nodes, uint64_t n_slots, RtRefitBox *root_out, uint32_t q8) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_nodes) return;
     const DevNode *nd = reinterpret_cast<const DevNode *>(chunks + (size_t)i * stride);
-    const int32_t refs[2] = {nd->ref0, nd->ref1};
+    // q8 records (stride 2) are the first 32 bytes of a DevNode; their references carry the scale exponent
+    const int32_t refs[2] = {q8 ? rt_q8_ref_load(nd->ref0) : nd->ref0, q8 ? rt_q8_ref_load(nd->ref1) : nd->ref1};
     uint32_t arrivals = 0;
     for (int child = 0; child < 2; child++) {
         if (refs[child] >= 0) continue;
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256) void rt_refit_nodes(float4 *__restrict__ chunk
         }
         const RtRefitBox b0 = cbox[2u * (size_t)cur], b1 = cbox[2u * (size_t)cur + 1u];
         DevNode *cn = reinterpret_cast<DevNode *>(chunks + (size_t)cur * stride);
-        rt_pack_children(*cn, b0.lo, b0.hi, b1.lo, b1.hi);
+        if (q8) rt_pack_children_q8(*cn, b0.lo, b0.hi, b1.lo, b1.hi, rt_q8_ref_load(cn->ref0), rt_q8_ref_load(cn->ref1));   // writes the first 32 bytes only
+        else rt_pack_children(*cn, b0.lo, b0.hi, b1.lo, b1.hi);
         RtRefitBox u = b0;
         grow(u, b1);
         const int32_t p = parent[cur];
@@ -97,11 +99,11 @@ __global__ __launch_bounds__(256) void rt_refit_nodes(float4 *__restrict__ chunk
 
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
-                           RtRefitBox *root_out, hipStream_t stream) {
+                           RtRefitBox *root_out, bool q8, hipStream_t stream) {
     if (n_slots == 0 || n_nodes == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(arrived, 0, (size_t)n_nodes * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     rt_refit_tris<<<dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream>>>(tris, shade, xform, tribox, n_slots);
-    rt_refit_nodes<<<dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream>>>(chunks, stride, parent, arrived, cbox, tribox, n_nodes, n_slots, root_out);
+    rt_refit_nodes<<<dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream>>>(chunks, stride, parent, arrived, cbox, tribox, n_nodes, n_slots, root_out, q8 ? 1u : 0u);
     return hipGetLastError();
 }

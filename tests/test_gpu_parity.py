@@ -586,9 +586,13 @@ def test_box_test_stays_conservative(rt, oracle_mod, obj_loader, case):
     want, want_hits, cnt = oracle_mod.OracleScene(s, build_bvh=False).render(
         oracle_mod.make_uniform(w, h, pos, yaw, pitch, **kw), mode=0, want_hits=True)
     assert (want_hits[..., 0] != 0xFFFFFFFF).mean() > 0.05, "the camera must see the scene for the test to mean anything"
-    for stride in (3, 4):
+    for stride in (3, 4, 2):                     # 2: the 32-byte node format (8-bit plane offsets), RT_OPT_NODE_FORMAT
         with rt.Context(0) as ctx:
-            ctx.set_option(rt.RT_OPT_NODE_STRIDE, stride)
+            if stride == 2:
+                ctx.set_option(rt.RT_OPT_NODE_FORMAT, 2)
+            else:
+                ctx.set_option(rt.RT_OPT_NODE_FORMAT, 1)
+                ctx.set_option(rt.RT_OPT_NODE_STRIDE, stride)
             ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
             ctx.set_option(rt.RT_OPT_AOV, 1)
             ctx.accum_resize(w, h)
@@ -624,7 +628,8 @@ def test_uniform_fields_are_honoured(rt, oracle_mod, oracle_scenes, ctxs, kw):
     assert np.array_equal(rgb.reshape(-1, 3), oracle_mod.capture_rgb8(want)) and np.array_equal(rgb.reshape(-1, 3), rt.capture_rgb8(got))
 
 
-def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes):
+@pytest.mark.parametrize("node_format", [1, 2])
+def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes, node_format):
     """RT_OPT_REFIT = 2: rt_models_update recomputes the triangle records and the node boxes ON the device
     (csrc/rt_refit.hip).  Same hit ids and image as the oracle for the moved geometry and as the host refit,
     over several updates in a row (the arrival counters are reused), with a material edit riding along, on a
@@ -646,6 +651,7 @@ def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes):
     with rt.Context(0) as dev, rt.Context(0) as host:
         for ctx, mode in ((dev, 2), (host, 1)):
             ctx.set_option(rt.RT_OPT_REFIT, mode)                       # before the upload: it keeps the topology on the device
+            ctx.set_option(rt.RT_OPT_NODE_FORMAT, node_format)          # 48-byte / 32-byte node records
             ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)   # no transforms at upload
             ctx.set_option(rt.RT_OPT_AOV, 1)
         for k, m in enumerate(moves):
@@ -677,6 +683,7 @@ def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes):
     want, want_hits, cnt = osc.render(oracle_mod.make_uniform(64, 36, cam["position"], cam["yaw"], cam["pitch"], **kw), mode=0, want_hits=True)
     with rt.Context(0) as ctx:
         ctx.set_option(rt.RT_OPT_REFIT, 2)
+        ctx.set_option(rt.RT_OPT_NODE_FORMAT, node_format)
         ctx.scene_upload(syn.vertices, syn.indices, syn.primitives, syn.models)
         ctx.spheres_upload(syn.spheres)
         ctx.set_option(rt.RT_OPT_AOV, 1)
@@ -780,3 +787,47 @@ def test_material_records_in_lds_or_memory(rt, oracle_mod, obj_loader, n_geo):
         ctx.set_option(rt.RT_OPT_AOV, 0)
         ctx.dispatch(rt.make_uniform(w, h, pos, yaw, **kw))
         assert_images_identical(ctx.accum_download(), want, f"{n_geo} materials, no AOV")
+
+
+@pytest.mark.gpu
+def test_node_format_choice_and_limits(rt, oracle_mod, oracle_scenes, scenes):
+    """RT_OPT_NODE_FORMAT: 32-byte nodes give the same bits as 48-byte ones (all three kernel variants decode them);
+    a scene too big for their 8-bit offsets gets 48-byte nodes all the same; a refit that moves the scene out of
+    their range falls back to a host rebuild."""
+    cfg = config("C3")
+    w, h = 96, 54
+    s = scenes("teapot-circle")
+    want, _, cnt = oracle_scenes("teapot-circle").render(uniforms_for(oracle_mod, cfg, w, h, samples=2), mode=1, want_hits=True)
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.RT_OPT_NODE_FORMAT, 2)
+        ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+        small = ctx.stats().bvh_bytes
+        for variant in (2, 0, 1):
+            ctx.set_option(rt.RT_OPT_KERNEL, variant)
+            ctx.accum_resize(w, h)
+            ctx.stats_reset()
+            ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=2))
+            assert ctx.stats().rays == cnt.rays
+            assert_images_identical(ctx.accum_download(), want, f"32-byte nodes, variant {variant}")
+        ctx.set_option(rt.RT_OPT_KERNEL, 2)
+        # blow the scene up past 2^18 units: the device refit must notice and rebuild with 48-byte nodes
+        big = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(s.primitives), 1))
+        big[:, 0] = big[:, 5] = big[:, 10] = 3.0e5
+        ctx.models_update(s.models, transforms=big)
+        assert ctx.stats().bvh_bytes > small
+        ctx.accum_resize(8, 8)
+        ctx.dispatch(uniforms_for(rt, cfg, 8, 8, samples=1))
+        assert np.isfinite(ctx.accum_download()).all()
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.RT_OPT_NODE_FORMAT, 1)
+        ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+        assert ctx.stats().bvh_bytes > small                      # 48-byte nodes
+        ctx.set_option(rt.RT_OPT_NODE_FORMAT, 0)
+        ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+        assert ctx.stats().bvh_bytes > small                      # by size: a 0.3 MB tree keeps the 48-byte format
+    v = s.vertices.copy()
+    v["position"] *= np.float32(1.0e5)
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.RT_OPT_NODE_FORMAT, 2)
+        ctx.scene_upload(v, s.indices, s.primitives, s.models)
+        assert ctx.stats().bvh_bytes > small                      # extent 2e7: 48-byte nodes
