@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-tris", type=int, default=400, help="per geometry")
+ap.add_argument("--node-format", type=int, default=0, help="RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte, 2 32-byte nodes")
 args = ap.parse_args()
 rt = graft.load_package()
 rng = np.random.default_rng(args.seed)
@@ -72,6 +73,7 @@ for it in range(args.iters):
     want, want_hits, cnt = oracle.OracleScene(scene, transforms=T, build_bvh=False).render(
         oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=0, want_hits=True)
     with rt.Context(0) as ctx:
+        ctx.set_option(rt.RT_OPT_NODE_FORMAT, args.node_format)
         ctx.scene_upload(V, I, P, M)
         ctx.models_update(M, transforms=T)               # device refit of the tree built for the untransformed scene
         ctx.set_option(rt.RT_OPT_AOV, 1)
