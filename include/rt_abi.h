@@ -188,7 +188,7 @@ typedef struct RtStats {
 
 #define RT_OPT_NODE_FORMAT     8   /* BVH node record of the NEXT scene upload: 1 = 48 bytes (f16 plane offsets, three 16-byte
                                       fetches per visit), 2 = 32 bytes (8-bit offsets and a per-node power-of-two scale, two
-                                      fetches; needs < 2^26 nodes, < 2^24 primitives and a scene extent <= 2^18, else 48-byte
+                                      fetches; needs a scene extent <= 2^18, else 48-byte
                                       nodes are used all the same), 0 (default) = 32 bytes when they fit and the nodes exceed
                                       16 MB (they then miss the caches and the smaller record wins), else 48.  Both are
                                       conservative: same image bits. */

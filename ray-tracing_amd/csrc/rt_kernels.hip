@@ -164,11 +164,10 @@ __device__ __forceinline__ void test_node(const float4 *n, const Slab &sl, float
     float t0x, t1x, t0y, t1y, t0z, t1z, s0x, s1x, s0y, s1y, s0z, s1z;
     if (q8) {
         // two-load node (rt_pack.h): 8-bit plane offsets in units of scale = 2^(e - 20), per axis [c0.lo, c1.lo, c0.hi, c1.hi]
-        const uint32_t r0 = __float_as_uint(a.w), r1 = b.w;
-        const uint32_t e5 = ((r0 >> 27) & 15u) | ((r1 >> 23) & 16u);
+        const uint32_t e5 = rt_q8_exponent(a.x, a.y);
         const float scale = __uint_as_float((e5 + (127u - RT_Q8_EXP_BIAS)) << 23);
-        refs.x = rt_q8_ref_load((int32_t)r0);
-        refs.y = rt_q8_ref_load((int32_t)r1);
+        refs.x = __float_as_int(a.w);
+        refs.y = (int32_t)b.w;
         const float sx = scale * sl.ix, sy = scale * sl.iy, sz = scale * sl.iz;
         auto ub = [](uint32_t v, int k) { return (float)((v >> (8 * k)) & 255u); };
         t0x = fmaf(ub(b.x, 0), sx, bx); t1x = fmaf(ub(b.x, 2), sx, bx);
@@ -681,10 +680,9 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                         // ENTERS through into bytes 0 and 1
                         const float4 a = ld4(n);
                         const uint4 b = ld4u(n + 1);
-                        const uint32_t r0 = __float_as_uint(a.w), r1 = b.w;
-                        const uint32_t e5 = ((r0 >> 27) & 15u) | ((r1 >> 23) & 16u);
+                        const uint32_t e5 = rt_q8_exponent(a.x, a.y);       // rides in the corner's lowest mantissa bits
                         const float scale = __uint_as_float((e5 + (127u - RT_Q8_EXP_BIAS)) << 23);
-                        refs = make_int2(rt_q8_ref_load((int32_t)r0), rt_q8_ref_load((int32_t)r1));
+                        refs = make_int2(__float_as_int(a.w), (int32_t)b.w);
                         const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
                         const float sx = scale * ix, sy = scale * iy, sz = scale * iz;
                         const uint32_t px = __builtin_amdgcn_alignbit(b.x, b.x, rx), py = __builtin_amdgcn_alignbit(b.y, b.y, ry),

@@ -56,19 +56,34 @@ RT_HD void rt_pack_children(DevNode &n, const float *blo0, const float *bhi0, co
 
 // Two-load node ("q8", RT_OPT_NODE_FORMAT): a 32-byte record = the first 32 bytes of a DevNode: the lower corner,
 // per axis one dword of four 8-bit plane offsets [c0.lo, c1.lo, c0.hi, c1.hi] in units of scale = 2^(e - 20), and the
-// two references with the 5-bit e in their spare bits 30..27 (ref0: e & 15, ref1: e >> 4).  Offsets are rounded
-// outward.  Needs references below 2^27 and node extents up to 255 * 2^11 (RT_Q8_MAX_EXTENT); the host falls back
-// to 48-byte nodes otherwise.  A third less node memory: 8 % faster where node fetches miss the caches (config C4),
-// 2 % slower where they do not (C3: the decode costs ~20 VALU instructions more per visit), hence chosen by size.
-#define RT_Q8_MAX_EXTENT 262144.0f
-#define RT_Q8_MAX_REF (1u << 27)
+// two references.  The 5-bit e rides in the lowest mantissa bits of the corner (lox: e & 7, loy: e >> 3); the corner
+// is moved DOWN to the next value with those bits, so the kernel uses the stuffed floats as they are.  Offsets are
+// rounded outward.  Node extents up to 255 * 2^11: the host falls back to 48-byte nodes for scenes beyond
+// RT_Q8_MAX_EXTENT.  A third less node memory: 8 % faster where node fetches miss the caches (config C4), 2 % slower
+// where they do not (C3: the decode costs ~20 VALU instructions more per visit), hence chosen by size.
 #define RT_Q8_EXP_BIAS 20
-RT_HD int32_t rt_q8_ref_store(int32_t ref, uint32_t ebits) { return (int32_t)(((uint32_t)ref & 0x87FFFFFFu) | (ebits << 27)); }
-RT_HD int32_t rt_q8_ref_load(int32_t stored) {
-    const uint32_t p = (uint32_t)stored & 0x87FFFFFFu;
-    return (int32_t)(p | ((uint32_t)((int32_t)p >> 31) & 0x78000000u));
+#define RT_Q8_MAX_EXTENT 262144.0f
+// largest float <= v whose low `nbits` mantissa bits are `bits` (v finite)
+RT_HD float rt_q8_stuff(float v, uint32_t bits, uint32_t nbits) {
+    const uint32_t mask = (1u << nbits) - 1u;
+    union { float f; uint32_t u; } x, y;
+    x.f = v;
+    if (!(v == v) || (x.u & 0x7f800000u) == 0x7f800000u) return v;       // NaN / inf: an empty box, never entered
+    y.u = (x.u & ~mask) | bits;
+    if (y.f > v) {
+        // step to the previous block of 2^nbits bit patterns: towards -inf
+        if ((x.u & 0x7fffffffu) < (1u << nbits) && !(x.u >> 31)) { y.u = 0x80000000u | (1u << nbits) | bits; }   // tiny positive: below zero
+        else if (x.u >> 31) y.u += 1u << nbits;     // negative: larger magnitude
+        else y.u -= 1u << nbits;                    // positive: smaller magnitude
+    }
+    return y.f;
 }
-RT_HD void rt_pack_children_q8(DevNode &n, const float *blo0, const float *bhi0, const float *blo1, const float *bhi1, int32_t ref0, int32_t ref1) {
+RT_HD uint32_t rt_q8_exponent(float lox, float loy) {
+    union { float f; uint32_t u; } x, y;
+    x.f = lox; y.f = loy;
+    return (x.u & 7u) | ((y.u & 3u) << 3);
+}
+RT_HD void rt_pack_children_q8(DevNode &n, const float *blo0, const float *bhi0, const float *blo1, const float *bhi1) {
     float lo0[3], hi0[3], lo1[3], hi1[3], lo[3];
     double ext = 0.0;
     for (int k = 0; k < 3; k++) {
@@ -76,11 +91,14 @@ RT_HD void rt_pack_children_q8(DevNode &n, const float *blo0, const float *bhi0,
         lo1[k] = rt_pad_lo(blo1[k]); hi1[k] = rt_pad_hi(bhi1[k]);
         lo[k] = lo0[k] < lo1[k] ? lo0[k] : lo1[k];
         const float hi = hi0[k] > hi1[k] ? hi0[k] : hi1[k];
-        const double d = (double)hi - (double)lo[k];
+        // the corner may still move down by up to 16 bit patterns (stuffing): 2^-19 of its magnitude, plus the denormal step
+        const double d = (double)hi - (double)lo[k] + fabs((double)lo[k]) * 1.9073486328125e-6 + 1e-37;
         if (d > ext) ext = d;
     }
     int e = 0;
     while (e < 31 && 255.0 * ldexp(1.0, e - RT_Q8_EXP_BIAS) < ext) e++;
+    lo[0] = rt_q8_stuff(lo[0], (uint32_t)e & 7u, 3);
+    lo[1] = rt_q8_stuff(lo[1], (uint32_t)e >> 3, 2);
     const double inv_scale = ldexp(1.0, RT_Q8_EXP_BIAS - e);
     uint32_t q[3];
     for (int k = 0; k < 3; k++) {
@@ -93,8 +111,6 @@ RT_HD void rt_pack_children_q8(DevNode &n, const float *blo0, const float *bhi0,
     }
     n.lox = lo[0]; n.loy = lo[1]; n.loz = lo[2];
     n.c0x = q[0]; n.c0y = q[1]; n.c0z = q[2];
-    n.ref0 = rt_q8_ref_store(ref0, (uint32_t)e & 15u);
-    n.ref1 = rt_q8_ref_store(ref1, (uint32_t)e >> 4);
 }
 
 // geometry transform of one corner, the host's expression (host/bvh_builder.cpp gather_triangles): every

@@ -59,8 +59,7 @@ __global__ __launch_bounds__(256) void rt_refit_nodes(float4 *__restrict__ chunk
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_nodes) return;
     const DevNode *nd = reinterpret_cast<const DevNode *>(chunks + (size_t)i * stride);
-    // q8 records (stride 2) are the first 32 bytes of a DevNode; their references carry the scale exponent
-    const int32_t refs[2] = {q8 ? rt_q8_ref_load(nd->ref0) : nd->ref0, q8 ? rt_q8_ref_load(nd->ref1) : nd->ref1};
+    const int32_t refs[2] = {nd->ref0, nd->ref1};      // q8 records (stride 2) are the first 32 bytes of a DevNode
     uint32_t arrivals = 0;
     for (int child = 0; child < 2; child++) {
         if (refs[child] >= 0) continue;
@@ -83,7 +82,7 @@ __global__ __launch_bounds__(256) void rt_refit_nodes(float4 *__restrict__ chunk
         }
         const RtRefitBox b0 = cbox[2u * (size_t)cur], b1 = cbox[2u * (size_t)cur + 1u];
         DevNode *cn = reinterpret_cast<DevNode *>(chunks + (size_t)cur * stride);
-        if (q8) rt_pack_children_q8(*cn, b0.lo, b0.hi, b1.lo, b1.hi, rt_q8_ref_load(cn->ref0), rt_q8_ref_load(cn->ref1));   // writes the first 32 bytes only
+        if (q8) rt_pack_children_q8(*cn, b0.lo, b0.hi, b1.lo, b1.hi);   // writes inside the first 32 bytes only
         else rt_pack_children(*cn, b0.lo, b0.hi, b1.lo, b1.hi);
         RtRefitBox u = b0;
         grow(u, b1);

@@ -830,4 +830,4 @@ def test_node_format_choice_and_limits(rt, oracle_mod, oracle_scenes, scenes):
     with rt.Context(0) as ctx:
         ctx.set_option(rt.RT_OPT_NODE_FORMAT, 2)
         ctx.scene_upload(v, s.indices, s.primitives, s.models)
-        assert ctx.stats().bvh_bytes > small                      # extent 2e7: 48-byte nodes
+        assert ctx.stats().bvh_bytes > small                      # extent 2e7 > 2^18: 48-byte nodes
