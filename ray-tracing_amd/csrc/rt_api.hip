@@ -397,10 +397,12 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     if (rp.node_stride == RT_NODE_CHUNKS) {
         RT_HIP(hipMemcpy(ctx->d_nodes, rp.nodes.data(), node_bytes, hipMemcpyHostToDevice));
     } else {
-        RT_HIP(hipMemset(ctx->d_nodes, 0, node_bytes));
-        const size_t row = rp.node_stride * 16u < sizeof(DevNode) ? rp.node_stride * 16u : sizeof(DevNode);
-        RT_HIP(hipMemcpy2D(ctx->d_nodes, (size_t)rp.node_stride * 16u, rp.nodes.data(), sizeof(DevNode), row, rp.nodes.size(),
-                           hipMemcpyHostToDevice));
+        // other strides (64-byte slots, 32-byte q8 records = the first 32 bytes of a DevNode): restride on the host and
+        // upload in one piece (a pitched copy of 10^8 32-byte rows takes minutes)
+        const size_t pitch = (size_t)rp.node_stride * 16u, row = pitch < sizeof(DevNode) ? pitch : sizeof(DevNode);
+        std::vector<uint8_t> packed(node_bytes ? node_bytes : 1, 0);
+        for (size_t i = 0; i < rp.nodes.size(); i++) memcpy(packed.data() + i * pitch, &rp.nodes[i], row);
+        RT_HIP(hipMemcpy(ctx->d_nodes, packed.data(), node_bytes, hipMemcpyHostToDevice));
     }
     ctx->node_bytes = node_bytes;
     ctx->node_stride = rp.node_stride;
