@@ -81,6 +81,7 @@ struct rt_context {
     DevTri *d_tris = nullptr;
     DevShade *d_shade = nullptr;
     DevMaterial *d_materials = nullptr;
+    size_t materials_capacity = 0;   // records d_materials holds
     uint64_t n_nodes = 0, n_tris = 0, node_bytes = 0;
     uint32_t stack_entries = 1;
     float scene_abs[3] = {0.0f, 0.0f, 0.0f};
@@ -394,6 +395,7 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     RT_HIP(hipMalloc((void **)&ctx->d_tris, rp.tris.size() * sizeof(DevTri)));
     RT_HIP(hipMalloc((void **)&ctx->d_shade, rp.shade.size() * sizeof(DevShade)));
     RT_HIP(hipMalloc((void **)&ctx->d_materials, mats.size() * sizeof(DevMaterial)));
+    ctx->materials_capacity = mats.size();
     if (rp.node_stride == RT_NODE_CHUNKS) {
         RT_HIP(hipMemcpy(ctx->d_nodes, rp.nodes.data(), node_bytes, hipMemcpyHostToDevice));
     } else {
@@ -792,7 +794,8 @@ int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_model
     // device refit: same primitives, same tree, and the sphere -> model references still valid
     bool spheres_ok = true;
     for (const RtSphere &sp : ctx->spheres) spheres_ok = spheres_ok && sp.model < n_models;
-    if (ctx->opt_refit == 2 && ctx->d_parent && ctx->n_nodes > 1 && spheres_ok) return device_refit(ctx);
+    // (and the material array as uploaded has room for the new models)
+    if (ctx->opt_refit == 2 && ctx->d_parent && ctx->n_nodes > 1 && spheres_ok && n_models <= ctx->materials_capacity) return device_refit(ctx);
     return build_and_upload(ctx, /*allow_refit=*/true);
 }
 

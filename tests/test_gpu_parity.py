@@ -831,3 +831,24 @@ def test_node_format_choice_and_limits(rt, oracle_mod, oracle_scenes, scenes):
         ctx.set_option(rt.RT_OPT_NODE_FORMAT, 2)
         ctx.scene_upload(v, s.indices, s.primitives, s.models)
         assert ctx.stats().bvh_bytes > small                      # extent 2e7 > 2^18: 48-byte nodes
+
+
+@pytest.mark.gpu
+def test_models_update_with_more_models_than_uploaded(rt, scenes):
+    """rt_models_update may bring MORE models than the upload had (only the first ones are referenced by geometries):
+    the material array on the device must grow (host path instead of the device refit) and the image stays the same."""
+    cfg = config("C2")
+    w, h = 64, 36
+    s = scenes("teapot")
+    with rt.Context(0) as ctx:
+        ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+        ctx.accum_resize(w, h)
+        ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=2))
+        before = ctx.accum_download()
+        more = np.zeros(len(s.models) + 20, s.models.dtype)
+        more[:len(s.models)] = s.models
+        more["diffuse_color"][len(s.models):] = (1.0, 0.0, 1.0)
+        ctx.models_update(more)
+        ctx.accum_resize(w, h)
+        ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=2))
+        assert_images_identical(ctx.accum_download(), before, "more models than uploaded")
