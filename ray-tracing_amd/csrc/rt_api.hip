@@ -582,7 +582,7 @@ int check_dispatch(rt_context *ctx, const RtUniform *u) {
                     u->window[0], u->window[1], ctx->width, ctx->height);
     if ((uint64_t)u->window[0] * u->window[1] > 0xFFFFFFFFull)
         return fail(RT_ERR_INVALID_ARGUMENT, "window has more than 2^32 pixels");
-    if ((uint64_t)ctx->stack_entries * 256u * 4u > 160u * 1024u)
+    if ((uint64_t)ctx->stack_entries * 256u * 4u + RT_LDS_MATERIALS * 64u > 160u * 1024u)      // traversal stacks + the material copy
         return fail(RT_ERR_INVALID_ARGUMENT, "BVH depth %u needs more LDS than a CU has", ctx->stack_entries);
     RT_HIP(hipSetDevice(ctx->device));
     if (ctx->opt_aov) { int r = ensure_aov(ctx); if (r) return r; }
