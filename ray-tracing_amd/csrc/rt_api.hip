@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <deque>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -270,12 +271,15 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
     memset(out.nodes.data(), 0, n_inner * sizeof(DevNode));
     out.parent.assign(n_inner, -1);
     struct Item { uint32_t src, dst; };
-    std::vector<Item> todo;
+    std::deque<Item> todo;
     todo.push_back({0u, 0u});
     uint32_t next = 1;
     while (!todo.empty()) {
-        Item it = todo.back();
-        todo.pop_back();
+        // the first RT_TOP_NODES nodes are numbered breadth-first (the top of the tree sits together at the start of
+        // the array), the rest depth-first
+        const bool bfs = next <= RT_TOP_NODES;
+        Item it = bfs ? todo.front() : todo.back();
+        if (bfs) todo.pop_front(); else todo.pop_back();
         const rt_host::Bvh2Node &n = bvh.nodes[it.src];
         DevNode &d = out.nodes[it.dst];
         const rt_host::Bvh2Node &c0 = bvh.nodes[n.left], &c1 = bvh.nodes[n.left + 1];
@@ -284,8 +288,13 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         if (c0.count) r0 = leaf_ref(c0); else { d0 = next++; r0 = (int32_t)(d0 * out.node_stride); out.parent[d0] = (int32_t)(it.dst * 2u); }
         if (c1.count) r1 = leaf_ref(c1); else { d1 = next++; r1 = (int32_t)(d1 * out.node_stride); out.parent[d1] = (int32_t)(it.dst * 2u + 1u); }
         set_children(d, c0.box, r0, c1.box, r1, out.q8);
-        if (!c1.count) todo.push_back({n.left + 1, d1});
-        if (!c0.count) todo.push_back({n.left, d0});
+        if (bfs) {
+            if (!c0.count) todo.push_back({n.left, d0});
+            if (!c1.count) todo.push_back({n.left + 1, d1});
+        } else {
+            if (!c1.count) todo.push_back({n.left + 1, d1});
+            if (!c0.count) todo.push_back({n.left, d0});
+        }
     }
     // a depth-first walk pushes at most one reference per inner node on the path: max_depth entries (+1 spare)
     out.stack_entries = bvh.max_depth + 1;
