@@ -227,6 +227,9 @@ def main():
                                "kernel": "rt_render_phased", "kernel_ms": kernel_ms, "frames_per_launch": args.steps / launches,
                                "bytes_per_ray": bytes_per_ray, "nodes_per_ray": model["nodes_per_ray"],
                                "tris_per_ray": model["tris_per_ray"], "hit_fraction": model["hit_fraction"], "byte_model": model_src}
+            if achieved > HBM_PEAK_GBS:
+                out["roofline"]["note"] = ("frac > 1: the scene's records are cache-resident, the algorithmic bytes are served by L1/L2 and "
+                                           "HBM carries `traffic` only; the kernel is bound by the L1 return path (DESIGN.md section 5)")
         print(json.dumps(out), flush=True)
 
     if args.verify and rank == 0:
