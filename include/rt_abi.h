@@ -272,6 +272,18 @@ int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames);
  * rt_accum_resize / rt_accum_bind), so that the dispatch itself does not allocate.  No
  * counterpart in the reference (its accumulation is one dispatch per frame). */
 int rt_frames_reserve(rt_context *ctx, uint32_t n_frames);
+/* rt_dispatch_frames for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same frame
+ * bookkeeping and the same bits in the accumulation buffer as rt_dispatch_frames, but the call makes no
+ * hipMalloc / hipFree: the scratch of the launch — the work-queue head and the per-frame staging planes — lives
+ * in a static device array of RT_STATIC_STAGE_BYTES (+256) bytes that every GPU the library runs on holds
+ * until the process ends.  The whole run is ONE launch, so n_frames x local_rows x w x 16 bytes must fit that
+ * array (n_frames = 1 stages nothing and fits at any size); a bigger request fails with
+ * RT_ERR_INVALID_ARGUMENT and a message naming both sizes, nothing is rendered.  RT_OPT_AOV must be off (its
+ * buffer is allocated on demand).  All contexts on one GPU share that GPU's array: calls that overlap on one
+ * GPU (two contexts, two streams) race; calls on one stream, or separated by rt_sync, do not. */
+#define RT_STATIC_STAGE_BYTES (32ull << 20)
+int rt_dispatch_frames_static(rt_context *ctx, RtUniform *uniform, uint32_t n_frames);
 int rt_sync(rt_context *ctx);
 
 /* ---------------------------------------------------------------- readback */

@@ -61,7 +61,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_option",
     "rt_scene_upload", "rt_spheres_upload", "rt_textures_upload", "rt_models_update",
     "rt_set_shard", "rt_accum_local_rows", "rt_accum_resize", "rt_accum_bind",
-    "rt_dispatch", "rt_dispatch_frames", "rt_frames_reserve", "rt_sync", "rt_capture_rgb8",
+    "rt_dispatch", "rt_dispatch_frames", "rt_dispatch_frames_static", "rt_frames_reserve", "rt_sync", "rt_capture_rgb8",
     "rt_accum_download", "rt_aov_download", "rt_stats", "rt_stats_reset", "rt_last_dispatch_ms",
     "rt_host_scene_load", "rt_host_scene_free", "rt_host_scene_vertex_count", "rt_host_scene_index_count",
     "rt_host_scene_model_count", "rt_host_scene_vertices", "rt_host_scene_indices", "rt_host_scene_primitives",
@@ -159,6 +159,7 @@ def lib():
         L.rt_accum_bind.argtypes = [vp, vp, u64, u32, u32]
         L.rt_dispatch.argtypes = [vp, vp]
         L.rt_dispatch_frames.argtypes = [vp, vp, u32]
+        L.rt_dispatch_frames_static.argtypes = [vp, vp, u32]
         L.rt_frames_reserve.argtypes = [vp, u32]
         L.rt_capture_rgb8.argtypes = [vp, vp]
         L.rt_sync.argtypes = [vp]
@@ -375,6 +376,11 @@ class Context:
         """Advances uniform['frame'] / ['accumulation_frame'] in place (src/app.rs:78-96)."""
         assert uniform.flags.c_contiguous and uniform.dtype.itemsize == 80
         _check(lib().rt_dispatch_frames(self.handle, uniform.ctypes.data, n_frames))
+
+    def dispatch_frames_static(self, uniform, n_frames):
+        """rt_dispatch_frames without any device allocation (static scratch, size-limited)."""
+        assert uniform.flags.c_contiguous and uniform.dtype.itemsize == 80
+        _check(lib().rt_dispatch_frames_static(self.handle, uniform.ctypes.data, n_frames))
 
     def capture_rgb8(self):
         """[local_rows, width, 3] uint8: the accumulation buffer through Capture's conversion, done on the device."""

@@ -60,6 +60,17 @@ void dev_free(T *&p) {
 
 }  // namespace
 
+// ---- static scratch of rt_dispatch_frames_static (rt_abi.h): callers that cannot allocate ----
+// One array per GPU (every device that loads this code object holds its own copy at its own address, until the
+// process ends): [0, 256) the work-queue head, then the per-frame staging planes of a multi-frame launch.
+// In host code the NAME is only a stand-in for the symbol; the device address comes from hipGetSymbolAddress,
+// taken once per device in rt_create with that device current, and only that pointer is ever handed to
+// kernels / hipMemsetAsync.
+#define RT_STATIC_HEADER_BYTES 256u
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_HEADER_BYTES + RT_STATIC_STAGE_BYTES];
+#define RT_MAX_DEVICES 64
+static void *g_scratch_ptr[RT_MAX_DEVICES];        // per device: address of `scratch` there, null until rt_create ran on it
+
 struct rt_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -484,15 +495,21 @@ int ensure_stage(rt_context *ctx, uint32_t n_frames) {
     return RT_OK;
 }
 
-int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
+// static_scratch: the queue head and the staging planes live in this device's `scratch` array (rt_dispatch_frames_static,
+// which has checked that they fit); nothing is allocated on that path.
+int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned char *static_scratch = nullptr) {
     RenderParams P;
     memset(&P, 0, sizeof P);
     P.n_frames = n_frames;
     P.local_rows = (uint32_t)local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count);
     if (n_frames > 1) {
-        int r = ensure_stage(ctx, n_frames);
-        if (r) return r;
-        P.stage = ctx->d_stage;
+        if (static_scratch) {
+            P.stage = reinterpret_cast<float4 *>(static_scratch + RT_STATIC_HEADER_BYTES);
+        } else {
+            int r = ensure_stage(ctx, n_frames);
+            if (r) return r;
+            P.stage = ctx->d_stage;
+        }
         P.stage_stride = (uint64_t)P.local_rows * ctx->width;
     }
     P.node_q8 = ctx->node_q8 ? 1u : 0u;
@@ -529,14 +546,14 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
     P.forward[0] = forward.x; P.forward[1] = forward.y; P.forward[2] = forward.z;
     P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
     P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
-    P.queue = ctx->d_queue;
+    P.queue = static_scratch ? reinterpret_cast<DevQueue *>(static_scratch) : ctx->d_queue;
     memcpy(P.tune, ctx->tune, sizeof P.tune);
     // queue grain: 64 slots (one 8x8 tile) keeps the end of a launch short, which is what counts for a shard of
     // the image; a whole 4K image takes two tiles per claim (measured: 16.8 -> 16.5 ms/step at 8.3 M slots per
     // frame, but 8.46 -> 8.65 ms/step at 4.1 M, so the switch sits between the two)
     P.chunk = ctx->chunk ? ctx->chunk : ((uint64_t)P.tiles_x * P.local_bands * 64u >= (6u << 20) ? 128u : 64u);
     if (ctx->opt_kernel != 1) {
-        RT_HIP(hipMemsetAsync(ctx->d_queue, 0, sizeof(DevQueue), ctx->stream));
+        RT_HIP(hipMemsetAsync(P.queue, 0, sizeof(DevQueue), ctx->stream));     // the head must start at zero, whatever the last call left
         const bool ext = !ctx->spheres.empty() || ctx->n_textures > 0;
         const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
         const int sel = (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
@@ -549,7 +566,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1) {
     }
 #ifdef RT_TAIL_PROBE
     const size_t probe_waves = (size_t)(ctx->persistent_blocks > 0 ? ctx->persistent_blocks : 0) * 4;
-    if (ctx->opt_kernel == 2 && n_frames > 1 && probe_waves) {
+    if (ctx->opt_kernel == 2 && n_frames > 1 && probe_waves && !static_scratch) {
         RT_HIP(hipMalloc((void **)&P.probe, probe_waves * 24));
         RT_HIP(hipMemsetAsync(P.probe, 0, probe_waves * 24, ctx->stream));
     }
@@ -649,6 +666,12 @@ int rt_create(int device_id, rt_context **out) {
     if (e != hipSuccess || n == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device (%s)", hipGetErrorString(e));
     if (device_id < 0 || device_id >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_id, n - 1);
     RT_HIP(hipSetDevice(device_id));
+    if (device_id < RT_MAX_DEVICES && !g_scratch_ptr[device_id]) {
+        // this device's copy of the static scratch array (rt_dispatch_frames_static); the device is current here
+        void *p = nullptr;
+        RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[device_id] = p;
+    }
     rt_context *ctx = new rt_context();
     ctx->device = device_id;
     (void)hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device_id);
@@ -896,6 +919,50 @@ int rt_dispatch_frames(rt_context *ctx, RtUniform *uniform, uint32_t n_frames) {
         r = launch(ctx, *uniform, group);
         if (r) return r;
         uniform->accumulation_frame += group - 1;          // the launch covered frames frame .. frame + group - 1
+        uniform->frame += group - 1;
+        i += group;
+    }
+    RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    return RT_OK;
+}
+
+int rt_dispatch_frames_static(rt_context *ctx, RtUniform *uniform, uint32_t n_frames) {
+    if (!ctx || !uniform) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    // everything check_dispatch checks, minus the one thing there that allocates (the AOV buffer)
+    if (ctx->opt_aov) return fail(RT_ERR_INVALID_ARGUMENT, "rt_dispatch_frames_static: RT_OPT_AOV needs a buffer this call may not allocate");
+    int r = check_dispatch(ctx, uniform);
+    if (r) return r;
+    unsigned char *sc = ctx->device < RT_MAX_DEVICES ? static_cast<unsigned char *>(g_scratch_ptr[ctx->device]) : nullptr;
+    if (!sc) return fail(RT_ERR_HIP, "rt_dispatch_frames_static: no static scratch on device %d", ctx->device);
+    if (n_frames == 0) return RT_OK;
+    // One launch for the whole run when the kernel can take it (as rt_dispatch_frames), with the staging planes in the
+    // static array: n_frames x local pixels x 16 bytes must fit.  Other kernel variants / RT_OPT_FRAME_PIPELINE = 0
+    // render frame by frame and stage nothing.
+    const uint64_t frame_slots = (uint64_t)((ctx->width + 7u) / 8u) * ctx->local_bands * 64u;
+    const bool pipelined = ctx->opt_pipeline && ctx->opt_kernel == 2 && ctx->width < 65536u && frame_slots != 0 && n_frames > 1;
+    if (pipelined) {
+        const uint64_t need = local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count) * ctx->width * sizeof(float4) * n_frames;
+        if (need > RT_STATIC_STAGE_BYTES)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_dispatch_frames_static: %u frames of this window need %llu bytes of staging, the static "
+                        "scratch holds %llu (use rt_dispatch_frames, or fewer frames per call)", n_frames, (unsigned long long)need,
+                        (unsigned long long)RT_STATIC_STAGE_BYTES);
+        if (frame_slots * n_frames > 0xFFFFFFFFull || n_frames > 65535u)
+            return fail(RT_ERR_INVALID_ARGUMENT, "rt_dispatch_frames_static: %u frames exceed the 32-bit work queue of one launch", n_frames);
+    }
+    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    uint32_t i = 0;
+    while (i < n_frames) {
+        const uint32_t group = pipelined ? n_frames : 1u;
+        uniform->accumulation_frame += 1;                  // src/app.rs:78
+        if (ctx->accum_fresh) {                            // src/app.rs:87-88
+            uniform->accumulation_frame = 0;
+            ctx->accum_fresh = false;
+        }
+        uniform->frame += 1;                               // src/app.rs:96
+        r = launch(ctx, *uniform, group, sc);
+        if (r) return r;
+        uniform->accumulation_frame += group - 1;
         uniform->frame += group - 1;
         i += group;
     }
