@@ -53,6 +53,7 @@ def lib():
         L.oracle_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_scene_triangles.restype = C.c_uint64
         L.oracle_scene_triangles.argtypes = [C.c_void_p]
+        L.oracle_threads.restype = C.c_int
         L.oracle_scene_nodes.restype = C.c_uint64
         L.oracle_scene_nodes.argtypes = [C.c_void_p]
         L.oracle_render_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,

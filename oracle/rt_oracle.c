@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <float.h>
+#include <omp.h>
 
 /* ------------------------------------------------------------ layouts ---- */
 /* restated from shaders/types.wgsl:1-57 + WGSL alignment rules; deliberately
@@ -749,6 +750,8 @@ void oracle_scene_set_front_face_cw(OScene *sc, int cw) { sc->front_face_cw = cw
 void oracle_scene_set_textures(OScene *sc, const uint8_t *const *textures, const uint32_t *w, const uint32_t *h, uint32_t n) {
     sc->textures = textures; sc->tex_w = w; sc->tex_h = h; sc->n_textures = n;
 }
+/* threads oracle_render_rows runs on (bench.py's cpu_baseline.cores) */
+int oracle_threads(void) { return omp_get_max_threads(); }
 uint64_t oracle_scene_triangles(const OScene *sc) { return sc->n_tris; }
 uint64_t oracle_scene_nodes(const OScene *sc) { return sc->n_nodes; }
 void oracle_scene_destroy(OScene *sc) {

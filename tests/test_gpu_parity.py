@@ -400,9 +400,9 @@ def test_bench_contract_and_sharded_image(ranks):
     env = dict(os.environ, RT_BENCH_BACKEND="gloo")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--verify",
            "--cpu-sample", "240x135"]
-    if ranks > 1:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
-               "--master-port", "29533"] + cmd[1:]
+    # ranks > 1: `python bench.py --gpus N` as typed — bench.py starts its own ranks (no torch.distributed.run around it)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=110, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
@@ -412,10 +412,14 @@ def test_bench_contract_and_sharded_image(ranks):
     m = metric[0]
     assert m["n_gpus"] == ranks and m["steps"] == 2 and m["unit"] == "Mrays/s" and m["value"] > 0
     assert m["config"]["rays"] > 3840 * 2160 * 16 * 2
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic"):
         assert key in m["roofline"]
+    assert 0.0 < m["roofline"]["frac"] <= 1.0          # measured HBM traffic against the HBM peak: a fraction that can bind
+    if "onchip" in m["roofline"]:
+        assert 0.0 < m["roofline"]["onchip"]["frac"] <= 1.05
     if ranks == 1:                                   # the CPU leg runs on rank 0 at N = 1 only
         assert m["cpu_baseline"]["kind"] == "port" and m["cpu_baseline"]["value"] > 0
+        assert 1 <= m["cpu_baseline"]["cores"] <= (os.cpu_count() or 1) and m["cpu_baseline"]["cpu_model"]
         assert m["parity"]["identical"] is True and m["parity"]["rays_equal"] is True
     else:
         assert "cpu_baseline" not in m

@@ -269,3 +269,18 @@ def test_host_half_under_sanitizers(tmp_path):
     if "ASan runtime does not come first" in r.stderr:
         pytest.skip("a preloaded library precedes the ASan runtime here")
     assert r.returncode == 0 and "host sanitize run ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_bench_self_launch_relays_failure():
+    """`python bench.py --gpus 2` as typed starts its own two ranks; without a GPU each rank refuses to run and
+    the parent must report that with a non-zero exit code (no silent success, no retry)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # also on a GPU box this test sees no device
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert "rank(s) failed" in r.stderr and "needs a GPU" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
