@@ -168,6 +168,8 @@ typedef struct RtStats {
     uint64_t launches;        /* render-kernel launches: rt_dispatch_frames folds a run of frames into one */
     uint32_t stack_entries;   /* static: traversal stack entries per lane (BVH depth + 1), 1 KiB of LDS each per workgroup */
     uint32_t resident_blocks; /* workgroups of 256 the persistent kernel keeps resident (0 before the first launch) */
+    uint64_t guard_trips;     /* librt_amd_guard.so only (make guard: every traversal reference range-checked, steps capped):
+                                 rays ended by a failed check.  Always 0 in the shipping library, which compiles no checks. */
 } RtStats;
 
 /* rt_set_option keys */
@@ -243,7 +245,8 @@ int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_model
  * belongs to shard t % shard_count.  A context renders only its bands and its
  * accumulation buffer holds only those rows, packed (band t is local band
  * t / shard_count).  pixel_idx stays global, so results are bit-identical to
- * an unsharded render.  Default 0 of 1.  Call before rt_accum_resize/bind. */
+ * an unsharded render.  Default 0 of 1.  Changing the shard drops the accumulation buffer
+ * (a bound one is un-bound): call rt_accum_resize / rt_accum_bind again afterwards. */
 int rt_set_shard(rt_context *ctx, uint32_t shard_index, uint32_t shard_count);
 /* Number of rows / bytes the local accumulation buffer holds for a w x h image. */
 uint64_t rt_accum_local_rows(const rt_context *ctx, uint32_t w, uint32_t h);

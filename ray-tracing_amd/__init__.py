@@ -114,7 +114,7 @@ class RtStats(C.Structure):
                 ("wave_steps", C.c_uint64), ("dispatches", C.c_uint64), ("bvh_nodes", C.c_uint64),
                 ("bvh_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double), ("bvh_refits", C.c_uint64),
                 ("bvh_rebuilds", C.c_uint64), ("launches", C.c_uint64),
-                ("stack_entries", C.c_uint32), ("resident_blocks", C.c_uint32)]
+                ("stack_entries", C.c_uint32), ("resident_blocks", C.c_uint32), ("guard_trips", C.c_uint64)]
 
 
 class RtBvhInfo(C.Structure):

@@ -98,6 +98,7 @@ struct rt_context {
     uint32_t stack_entries = 1;
     float scene_abs[3] = {0.0f, 0.0f, 0.0f};
     bool have_scene = false;
+    bool models_committed = false;   // the last build_and_upload / device_refit got as far as changing device state
     rt_host::Bvh2 bvh;               // kept for host refits (rt_models_update)
     // device refit (RT_OPT_REFIT = 2): topology + scratch, uploaded with the scene
     int32_t *d_parent = nullptr;     // per node: parent * 2 + child slot, root -1
@@ -118,6 +119,8 @@ struct rt_context {
     bool accum_fresh = false;
     uint32_t *d_aov = nullptr;
     uint64_t aov_elems = 0;
+    uint8_t *d_rgb = nullptr;        // rt_capture_rgb8's device buffer
+    uint64_t rgb_bytes = 0;
 
     DevCounters *d_counters = nullptr;
     DevQueue *d_queue = nullptr;
@@ -331,6 +334,7 @@ void convert_materials(const rt_context &ctx, std::vector<DevMaterial> &mats) {
 }
 
 int build_and_upload(rt_context *ctx, bool allow_refit = false) {
+    ctx->models_committed = false;
     std::string err;
     std::vector<float> corners;
     std::vector<uint32_t> ids;
@@ -391,14 +395,7 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     {
         // Node format (rt_pack.h): 32-byte q8 records when the scene's extent fits AND the nodes are too
         // many to stay in the caches (measured: C4, 244 MB of 48-byte nodes, 8 % faster; C3, 0.26 MB, 2 % slower)
-        float ext = 0.0f;
-        bool finite = true;
-        for (int k = 0; k < 3 && n_prims; k++) {
-            const float d = bvh.nodes[0].box.hi[k] - bvh.nodes[0].box.lo[k];
-            if (!(d <= 3.0e38f)) finite = false;
-            ext = fmaxf(ext, d);
-        }
-        const bool fits = finite && ext <= RT_Q8_MAX_EXTENT;
+        const bool fits = n_prims > 0 && rt_q8_fits(bvh.nodes[0].box.lo, bvh.nodes[0].box.hi);
         rp.q8 = fits && (ctx->opt_node_format == 2 || (ctx->opt_node_format == 0 && bvh.nodes.size() * sizeof(DevNode) / 2 >= (16ull << 20)));
         if (rp.q8) rp.node_stride = 2;
     }
@@ -409,6 +406,8 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
 
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->models_committed = true;    // from here on the device scene is being replaced
+    ctx->have_scene = false;
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
     const size_t node_bytes = rp.nodes.size() * (size_t)rp.node_stride * 16u;
     RT_HIP(hipMalloc((void **)&ctx->d_nodes, node_bytes));
@@ -515,7 +514,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
     P.node_q8 = ctx->node_q8 ? 1u : 0u;
     P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
     P.textures = ctx->d_textures; P.texels = ctx->d_texels; P.n_textures = ctx->n_textures;
-    P.n_materials = (uint32_t)(ctx->models.size() ? ctx->models.size() : 1);
+    P.n_materials = (uint32_t)ctx->materials_capacity;      // records actually uploaded (the LDS preload copies that many)
     P.accum = ctx->d_accum;
     P.aov = ctx->opt_aov ? ctx->d_aov : nullptr;
     P.counters = ctx->d_counters;
@@ -546,6 +545,8 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
     P.forward[0] = forward.x; P.forward[1] = forward.y; P.forward[2] = forward.z;
     P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
     P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
+    P.n_node_chunks = (uint32_t)(ctx->node_bytes / 16u);
+    P.n_slots = ctx->n_tris;
     P.queue = static_scratch ? reinterpret_cast<DevQueue *>(static_scratch) : ctx->d_queue;
     memcpy(P.tune, ctx->tune, sizeof P.tune);
     // queue grain: 64 slots (one 8x8 tile) keeps the end of a launch short, which is what counts for a shard of
@@ -619,6 +620,7 @@ int check_dispatch(rt_context *ctx, const RtUniform *u) {
 int device_refit(rt_context *ctx) {
     auto t0 = std::chrono::steady_clock::now();
     RT_HIP(hipSetDevice(ctx->device));
+    ctx->models_committed = true;
     std::vector<DevMaterial> mats;
     convert_materials(*ctx, mats);
     RT_HIP(hipMemcpyAsync(ctx->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice, ctx->stream));
@@ -645,9 +647,7 @@ int device_refit(rt_context *ctx) {
     if (ctx->node_q8) {
         // the moved scene may have outgrown what 8-bit offsets can span (their outward rounding saturates there):
         // rebuild on the host, which chooses the node format again
-        float ext = 0.0f;
-        for (int k = 0; k < 3; k++) ext = fmaxf(ext, root.hi[k] - root.lo[k]);
-        if (!(ext <= RT_Q8_MAX_EXTENT)) return build_and_upload(ctx, true);
+        if (!rt_q8_fits(root.lo, root.hi)) return build_and_upload(ctx, true);
     }
     return RT_OK;
 }
@@ -694,6 +694,7 @@ int rt_destroy(rt_context *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
     if (ctx->accum_owned) dev_free(ctx->d_accum);
+    dev_free(ctx->d_rgb);
     dev_free(ctx->d_aov); dev_free(ctx->d_counters); dev_free(ctx->d_queue); dev_free(ctx->d_stage);
     dev_free(ctx->d_parent); dev_free(ctx->d_arrived); dev_free(ctx->d_cbox); dev_free(ctx->d_tribox); dev_free(ctx->d_root); dev_free(ctx->d_xform);
     dev_free(ctx->d_textures); dev_free(ctx->d_texels);
@@ -738,6 +739,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
         default:
             // developer knobs (tools/ab_bench.py, tools/shard_scaling.py): 100..107 scheduler weights (103: resident workgroups per CU, 0 = all that fit) and builder leaf size /
             // bins, 108 queue grain, 109 staging budget in KiB, 110 SAH traversal cost x16, 111 BVH depth cap
+            if (key == 106 && (value < 0 || value > 7)) return fail(RT_ERR_INVALID_ARGUMENT, "option 106 (triangles per leaf): 0..7");
             if (key >= 100 && key < 108) {
                 ctx->tune[key - 100] = (int32_t)value;
                 if (key == 103) ctx->persistent_blocks = 0;     // grid size is recomputed at the next launch
@@ -821,20 +823,45 @@ int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_model
         for (size_t g = 0; g < ctx->primitives.size(); g++)
             if (ctx->primitives[g].transformation_offset >= ctx->primitives.size())
                 return fail(RT_ERR_INVALID_ARGUMENT, "geometry %zu: transformation_offset out of range", g);
-    ctx->models.assign(models, models + n_models);
-    if (transforms) ctx->transforms.assign(transforms, transforms + 12ull * ctx->primitives.size());
-    // device refit: same primitives, same tree, and the sphere -> model references still valid
+    // The device refit re-derives triangles from the shading records baked at upload, which took their vertices from the
+    // models' vertex_start / index_start (main.wgsl:86-91): it is only valid while those ranges are what was uploaded.
+    bool ranges_kept = n_models >= ctx->models.size();
+    for (size_t g = 0; g < ctx->models.size() && ranges_kept; g++)
+        ranges_kept = models[g].vertex_start == ctx->models[g].vertex_start && models[g].index_start == ctx->models[g].index_start;
     bool spheres_ok = true;
     for (const RtSphere &sp : ctx->spheres) spheres_ok = spheres_ok && sp.model < n_models;
-    // (and the material array as uploaded has room for the new models)
-    if (ctx->opt_refit == 2 && ctx->d_parent && ctx->n_nodes > 1 && spheres_ok && n_models <= ctx->materials_capacity) return device_refit(ctx);
-    return build_and_upload(ctx, /*allow_refit=*/true);
+    // commit the new models / transforms only once the path taken has accepted them
+    std::vector<RtGpuModel> old_models(models, models + n_models);
+    std::vector<float> old_transforms;
+    old_models.swap(ctx->models);
+    if (transforms) {
+        old_transforms.assign(transforms, transforms + 12ull * ctx->primitives.size());
+        old_transforms.swap(ctx->transforms);
+    }
+    int r;
+    // device refit: same primitives, same tree, same model ranges, the sphere -> model references still valid and the
+    // material array as uploaded has room for the new models
+    if (ctx->opt_refit == 2 && ctx->d_parent && ctx->n_nodes > 1 && ranges_kept && spheres_ok && n_models <= ctx->materials_capacity) r = device_refit(ctx);
+    else r = build_and_upload(ctx, /*allow_refit=*/true);
+    if (r != RT_OK && !ctx->models_committed) {       // rejected before anything reached the device: the old scene stays in force
+        old_models.swap(ctx->models);
+        if (transforms) old_transforms.swap(ctx->transforms);
+    }
+    return r;
 }
 
 int rt_set_shard(rt_context *ctx, uint32_t shard_index, uint32_t shard_count) {
     if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
     if (shard_count == 0 || shard_index >= shard_count) return fail(RT_ERR_INVALID_ARGUMENT, "shard %u of %u", shard_index, shard_count);
-    if (ctx->d_accum) return fail(RT_ERR_INVALID_ARGUMENT, "rt_set_shard must precede rt_accum_resize/rt_accum_bind");
+    if (ctx->d_accum && (shard_index != ctx->shard_index || shard_count != ctx->shard_count)) {
+        // the accumulation buffer was laid out for the old shard: drop it (a bound buffer is only un-bound)
+        RT_HIP(hipSetDevice(ctx->device));
+        RT_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->accum_owned) dev_free(ctx->d_accum);
+        ctx->d_accum = nullptr;
+        ctx->accum_owned = false;
+        ctx->width = ctx->height = 0;
+    }
     ctx->shard_index = shard_index;
     ctx->shard_count = shard_count;
     return RT_OK;
@@ -994,12 +1021,16 @@ int rt_capture_rgb8(rt_context *ctx, uint8_t *dst) {
     RT_HIP(hipSetDevice(ctx->device));
     const uint64_t n_pixels = local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count) * ctx->width;
     if (n_pixels == 0) return RT_OK;
-    uint8_t *d_rgb = nullptr;
-    RT_HIP(hipMalloc((void **)&d_rgb, n_pixels * 3));
-    hipError_t e = rt_launch_capture(ctx->d_accum, d_rgb, n_pixels, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(dst, d_rgb, n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream);
+    if (ctx->rgb_bytes < n_pixels * 3) {                   // kept between captures, grows with the window
+        RT_HIP(hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->d_rgb);
+        ctx->rgb_bytes = 0;
+        RT_HIP(hipMalloc((void **)&ctx->d_rgb, n_pixels * 3));
+        ctx->rgb_bytes = n_pixels * 3;
+    }
+    hipError_t e = rt_launch_capture(ctx->d_accum, ctx->d_rgb, n_pixels, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dst, ctx->d_rgb, n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_rgb);
     if (e != hipSuccess) return fail(RT_ERR_HIP, "rt_capture_rgb8: %s", hipGetErrorString(e));
     return RT_OK;
 }
@@ -1028,6 +1059,7 @@ int rt_stats(rt_context *ctx, RtStats *out) {
     out->wave_node_iters = c.wave_node_iters;
     out->wave_leaf_iters = c.wave_leaf_iters;
     out->wave_steps = c.wave_steps;
+    out->guard_trips = c.guard_trips;
     out->dispatches = ctx->dispatches;
     out->bvh_nodes = ctx->n_nodes;
     out->bvh_bytes = ctx->node_bytes + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));

@@ -85,7 +85,7 @@ struct RtRefitBox {
 struct DevCounters {
     unsigned long long rays, pixel_frames, node_visits, triangle_tests;
     unsigned long long wave_node_iters, wave_leaf_iters, wave_steps;
-    unsigned long long pad;
+    unsigned long long guard_trips;      // RT_GUARD builds: rays ended by a failed range check or the step cap (must stay 0)
 };
 
 // persistent-kernel work queue head: next unclaimed pixel slot of the launch
@@ -135,6 +135,10 @@ struct RenderParams {
     float forward[3], right[3], up[3];   // ray_direction's basis (shaders/ray.wgsl:2-4), hoisted to the host
     float aspect, fov_scale;             // ctx.camera.aspect, tan(fov/2) (shaders/ray.wgsl:6-7)
     float scene_abs[3];                  // max |coordinate| of the BVH root box per axis (slab-test error bound)
+    // RT_GUARD builds (make guard): what traversal references are checked against before they are used
+    uint32_t n_node_chunks;              // 16-byte chunks in the node array
+    uint32_t guard_pad;
+    uint64_t n_slots;                    // triangle / sphere records
     int32_t tune[8];                     // scheduler weights: [0] NODE, [1] LEAF, [2] SHADE, [4] FETCH (others unused by the kernel)
 #ifdef RT_TAIL_PROBE
     // developer build (make EXTRA=-DRT_TAIL_PROBE): per wave {start, first empty claim, exit} in 100 MHz ticks,

@@ -65,8 +65,17 @@ struct Hit {
 };
 
 struct Tally {      // per-lane counters; the wave-level ones only in counting builds
-    unsigned rays = 0, pixel_frames = 0, nodes = 0, tris = 0, w_nodes = 0, w_leaf = 0, w_steps = 0;
+    unsigned rays = 0, pixel_frames = 0, nodes = 0, tris = 0, w_nodes = 0, w_leaf = 0, w_steps = 0, guard = 0;
 };
+// RT_GUARD builds (`make guard` -> librt_amd_guard.so, tests/test_gpu_guard.py): every traversal reference is range-checked
+// before it is used, stack pointers are bounded and a ray's traversal steps are capped.  A failed check ends the ray and
+// counts in DevCounters::guard_trips instead of faulting the GPU.  The shipping build compiles none of it.
+#ifdef RT_GUARD
+constexpr bool kGuard = true;
+#else
+constexpr bool kGuard = false;
+#endif
+constexpr unsigned kGuardMaxSteps = 1u << 22;    // node + leaf steps one ray may take
 
 __device__ __forceinline__ float4 ld4(const void *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ bool first_active_lane() {
@@ -498,8 +507,8 @@ __device__ __forceinline__ Camera load_camera(const RenderParams &P) {
 // exact device-side counters: one atomic per wave per counter
 template <bool COUNT>
 __device__ __forceinline__ void flush_tally(const RenderParams &P, const Tally &tl) {
-    unsigned long long v[7] = {tl.rays, tl.pixel_frames, tl.nodes, tl.tris, tl.w_nodes, tl.w_leaf, tl.w_steps};
-    const int n = COUNT ? 7 : 2;
+    unsigned long long v[8] = {tl.rays, tl.pixel_frames, tl.nodes, tl.tris, tl.w_nodes, tl.w_leaf, tl.w_steps, tl.guard};
+    const int n = kGuard ? 8 : (COUNT ? 7 : 2);
     for (int k = 0; k < n; k++)
         for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
     if ((threadIdx.x & 63u) == 0) {
@@ -622,6 +631,8 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     bool have_pixel = false;  // FETCH: a finished pixel-frame waits to be written out
     int32_t cur = 0;          // NODE: inner node reference (float4 index); LEAF: leaf reference (< 0)
     uint32_t *sptr = stack;   // next free entry of the lane's LDS stack (entries are kBlock words apart)
+    unsigned guard_steps = 0; // RT_GUARD: traversal steps of the current ray
+    uint32_t *const stack_end = stack + (size_t)P.stack_entries * kBlock;
     uint32_t w_next = 0, w_end = 0;   // the wave's claimed chunk, wave-uniform
     bool drained = false;
 
@@ -637,6 +648,7 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                                      fmaf(P.scene_abs[2], fabsf(iz), fabsf(oz)));   // see make_slab
         best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
         cur = 0; sptr = stack;
+        guard_steps = 0;
         phase = PH_NODE;
     };
     // wave-uniform choice of the next phase body: the one most lanes wait for,
@@ -667,6 +679,8 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 for (int rep = 0; rep < RT_NODE_REPS; rep++) {
                 // back to the scheduler early once fewer than 1/RT_NODE_EARLY_OUT of the lanes that came in are still on nodes
                 if (rep > 0 && __popcll(__ballot(phase == PH_NODE)) * RT_NODE_EARLY_OUT < node_lanes) break;
+                if (kGuard && phase == PH_NODE &&
+                    ((uint32_t)cur + (Q8 ? 2u : 3u) > P.n_node_chunks || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
                 if (phase == PH_NODE) {
                     if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
                     const float4 *n = nodes + cur;
@@ -713,7 +727,10 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                     // next reference: the nearer hit child; the other one (if hit) is pushed
                     const bool take1 = h1 && (!h0 || n1 < n0);
                     int32_t nxt = take1 ? refs.y : refs.x;
-                    if (h0 && h1) { *sptr = (uint32_t)(take1 ? refs.x : refs.y); sptr += kBlock; }
+                    if (h0 && h1) {
+                        if (kGuard && sptr >= stack_end) { tl.guard++; }       // would overflow the lane's stack: the far child is dropped
+                        else { *sptr = (uint32_t)(take1 ? refs.x : refs.y); sptr += kBlock; }
+                    }
                     bool finished = false;
                     if (!(h0 || h1)) {
                         if (sptr == stack) { finished = true; }
@@ -730,6 +747,8 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
             do {
 #pragma unroll
                 for (int rep = 0; rep < RT_LEAF_REPS; rep++) {
+                if (kGuard && phase == PH_LEAF &&
+                    ((uint64_t)((uint32_t)~cur >> 3) + ((uint32_t)~cur & 7u) > P.n_slots || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
                 if (phase == PH_LEAF) {
                     // ~cur = first_slot << 3 | triangles left: tested last to first, the count runs down in place
                     uint32_t enc = (uint32_t)~cur;
@@ -934,10 +953,10 @@ hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool
     if (tiles == 0) return hipSuccess;
     const size_t lds = (size_t)P.stack_entries * kBlock * sizeof(uint32_t);
     dim3 tile_grid((tiles + (kBlock / 64) - 1) / (kBlock / 64));
-    // persistent grids: no more waves than chunks of work
-    uint32_t chunks = (tiles * 64u + P.chunk - 1) / P.chunk;
+    // persistent grids: no more waves than chunks of work in the WHOLE launch (all its frames), counted in 64 bits
+    const uint64_t chunks = ((uint64_t)tiles * 64u * (P.n_frames ? P.n_frames : 1u) + P.chunk - 1) / P.chunk;
     uint32_t blocks = (uint32_t)persistent_blocks;
-    if (blocks > (chunks + 3) / 4) blocks = (chunks + 3) / 4;
+    if ((uint64_t)blocks > (chunks + 3) / 4) blocks = (uint32_t)((chunks + 3) / 4);
     if (blocks == 0) blocks = 1;
     dim3 pgrid(blocks);
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);

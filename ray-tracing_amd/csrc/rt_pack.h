@@ -83,6 +83,18 @@ RT_HD uint32_t rt_q8_exponent(float lox, float loy) {
     x.f = lox; y.f = loy;
     return (x.u & 7u) | ((y.u & 3u) << 3);
 }
+// Can every node of a tree whose root box is [lo, hi] be written as a q8 record?  A node's offsets span its padded extent
+// plus what stuffing may move its corner down (2^-19 of the corner's magnitude), in units of at most 2^11: no node of the
+// tree needs more than the root's padded extent plus 2^-19 of the root's largest |coordinate|.
+RT_HD bool rt_q8_fits(const float *lo, const float *hi) {
+    for (int k = 0; k < 3; k++) {
+        const double l = rt_pad_lo(lo[k]), h = rt_pad_hi(hi[k]);
+        const double m = fabs(l) > fabs(h) ? fabs(l) : fabs(h);
+        const double d = (h - l) + m * 1.9073486328125e-6 + 1e-37;
+        if (!(d <= 255.0 * 2048.0) || !(d <= (double)RT_Q8_MAX_EXTENT)) return false;
+    }
+    return true;
+}
 RT_HD void rt_pack_children_q8(DevNode &n, const float *blo0, const float *bhi0, const float *blo1, const float *bhi1) {
     float lo0[3], hi0[3], lo1[3], hi1[3], lo[3];
     double ext = 0.0;

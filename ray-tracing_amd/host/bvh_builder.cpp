@@ -207,7 +207,7 @@ void build_bvh2(const Aabb *boxes, uint64_t n, const BvhBuildOptions &opt_in, Bv
     auto t0 = std::chrono::steady_clock::now();
     BvhBuildOptions opt = opt_in;
     if (opt.max_leaf == 0) opt.max_leaf = 4;
-    if (opt.max_leaf > 8) opt.max_leaf = 8;
+    if (opt.max_leaf > 7) opt.max_leaf = 7;      // a leaf reference keeps its count in 3 bits (rt_device.h dev_leaf_ref)
     if (opt.bins < 4) opt.bins = 4;
     if (opt.bins > 32) opt.bins = 32;
     // depth bound must leave room for a balanced tree over n primitives

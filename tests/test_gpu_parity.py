@@ -856,3 +856,68 @@ def test_models_update_with_more_models_than_uploaded(rt, scenes):
         ctx.accum_resize(w, h)
         ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=2))
         assert_images_identical(ctx.accum_download(), before, "more models than uploaded")
+
+
+@pytest.mark.gpu
+def test_models_update_changed_ranges_and_rejected_update(rt, oracle_mod, obj_loader, scenes):
+    """rt_models_update with a model whose vertex_start changed AFTER the upload: the device refit would keep shading with
+    the records baked at upload, so the call must take the host path — both refit modes give the oracle's image for the
+    new models.  And an update the library rejects (ranges beyond the buffers) must leave the uploaded scene in force."""
+    cfg = config("C2")
+    w, h = 64, 36
+    s = scenes("teapot")
+    n = len(s.vertices)
+    v2 = np.zeros(2 * n, obj_loader.VERTEX_DTYPE)
+    v2[:n] = s.vertices
+    v2[n:] = s.vertices
+    v2["normal"][n:] *= np.float32(-0.5)               # the second copy shades differently
+    new_models = s.models.copy()
+    new_models["vertex_start"][0] += n
+    ident = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (len(s.primitives), 1))
+    want, _, cnt = oracle_mod.OracleScene(obj_loader.Scene(v2, s.indices, s.primitives, new_models), transforms=ident).render(
+        uniforms_for(oracle_mod, cfg, w, h, samples=2), mode=1)
+    before, _, _ = oracle_mod.OracleScene(obj_loader.Scene(v2, s.indices, s.primitives, s.models), transforms=ident).render(
+        uniforms_for(oracle_mod, cfg, w, h, samples=2), mode=1)
+    assert not np.array_equal(want, before)
+    for refit in (2, 1):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.RT_OPT_REFIT, refit)
+            ctx.scene_upload(v2, s.indices, s.primitives, s.models, transforms=ident)
+            # rejected: a vertex range past the end of the vertex buffer
+            bad = s.models.copy()
+            bad["vertex_start"][1] = 2 * n
+            with pytest.raises(rt.RtError):
+                ctx.models_update(bad, transforms=ident)
+            ctx.accum_resize(w, h)
+            ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=2))
+            assert_images_identical(ctx.accum_download(), before, f"refit {refit}: scene after a rejected update")
+            ctx.models_update(new_models, transforms=ident)
+            ctx.accum_resize(w, h)
+            ctx.stats_reset()
+            ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=2))
+            assert ctx.stats().rays == cnt.rays
+            assert_images_identical(ctx.accum_download(), want, f"refit {refit}: model ranges changed by rt_models_update")
+
+
+@pytest.mark.gpu
+def test_set_shard_after_accumulation_buffer(rt, ctxs):
+    """rt_set_shard on a context that already has an accumulation buffer drops that buffer instead of failing; after a new
+    rt_accum_resize the context renders the new shard."""
+    cfg = config("C1")
+    w, h = 40, 40
+    ctx = ctxs("cornell-box")
+    try:
+        ctx.accum_resize(w, h)
+        ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=1))
+        full = ctx.accum_download()
+        ctx.set_shard(1, 2)
+        with pytest.raises(rt.RtError):                       # no buffer any more
+            ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=1))
+        ctx.accum_resize(w, h)
+        ctx.dispatch(uniforms_for(rt, cfg, w, h, samples=1))
+        part = ctx.accum_download()
+        rows = [y for y in range(h) if (y // 8) % 2 == 1]
+        assert part.shape[0] == len(rows)
+        assert_images_identical(part, full[rows], "shard 1 of 2 after re-sharding")
+    finally:
+        ctx.set_shard(0, 1)
