@@ -305,6 +305,46 @@ int rt_stats_reset(rt_context *ctx);
  * measured with HIP events on the context's stream.  Synchronises. */
 int rt_last_dispatch_ms(rt_context *ctx, float *ms);
 
+/* ------------------------------------------------------- several GPUs, one host object */
+/* ≙ SURVEY §8(b) `create(device_ids[], n)`: the reference has ONE context that owns every resource of the pass
+ * (Gpu::builder()…build() and the bindings, src/main.rs:27-59); an rt_group is that object for n GPUs of one node, so
+ * that the Rust host reaches all of them through this FFI from its one thread.  Shard i (bands i, i+n, … of 8 rows,
+ * rt_set_shard) renders on device_ids[i]; the same device may be named more than once (rehearsal on one GPU).
+ *   - rt_group_scene_upload / rt_group_spheres_upload validate, build and repack the scene ONCE on the host (one host
+ *     copy of the inputs, one BVH) and upload the result to every device;
+ *   - rt_group_models_update ≙ App::upload_models (src/app.rs:46-62): every device refits its own copy (or, when a
+ *     rebuild is needed, the host rebuilds once and every device receives the result);
+ *   - rt_group_dispatch / rt_group_dispatch_frames launch every shard on its own device and stream and return at
+ *     once (the devices render concurrently); *uniform advances exactly as in rt_dispatch_frames;
+ *   - rt_group_accum_download / rt_group_capture_rgb8 gather the shards' bands on device_ids[0] (peer copies, xGMI),
+ *     de-interleave them there in one kernel and hand back the WHOLE w x h image (16 B or 3 B per pixel): the same
+ *     bytes as a one-GPU rt_accum_download / rt_capture_rgb8;
+ *   - rt_group_stats sums the device-side counters over the shards (static figures are the first device's);
+ *   - rt_group_context gives shard i's rt_context for per-device calls (rt_last_dispatch_ms, rt_set_stream, …). */
+typedef struct rt_group rt_group;
+int rt_group_create(const int *device_ids, int n_devices, rt_group **out);
+int rt_group_destroy(rt_group *g);
+int rt_group_size(const rt_group *g);
+int rt_group_context(rt_group *g, int shard, rt_context **out);
+int rt_group_set_option(rt_group *g, int key, int64_t value);
+int rt_group_scene_upload(rt_group *g,
+                          const RtVertex *vertices, uint64_t n_vertices,
+                          const uint32_t *indices, uint64_t n_indices,
+                          const RtGeometryPrimitive *primitives, uint32_t n_primitives,
+                          const float *transforms,
+                          const RtGpuModel *models, uint32_t n_models);
+int rt_group_spheres_upload(rt_group *g, const RtSphere *spheres, uint64_t n_spheres);
+int rt_group_textures_upload(rt_group *g, const RtTexture *textures, uint32_t n_textures);
+int rt_group_models_update(rt_group *g, const RtGpuModel *models, uint32_t n_models, const float *transforms);
+int rt_group_accum_resize(rt_group *g, uint32_t w, uint32_t h);
+int rt_group_dispatch(rt_group *g, const RtUniform *uniform);
+int rt_group_dispatch_frames(rt_group *g, RtUniform *uniform, uint32_t n_frames);
+int rt_group_sync(rt_group *g);
+int rt_group_accum_download(rt_group *g, float *dst);
+int rt_group_capture_rgb8(rt_group *g, uint8_t *dst);
+int rt_group_stats(rt_group *g, RtStats *out);
+int rt_group_stats_reset(rt_group *g);
+
 /* ------------------------------------------------- host side (no GPU use) */
 /* Host mirror of the reference's Rust host for this path.  These run on the
  * CPU only and are what the Rust host keeps doing in the reference. */

@@ -63,6 +63,9 @@ EXPORTS = [
     "rt_set_shard", "rt_accum_local_rows", "rt_accum_resize", "rt_accum_bind",
     "rt_dispatch", "rt_dispatch_frames", "rt_dispatch_frames_static", "rt_frames_reserve", "rt_sync", "rt_capture_rgb8",
     "rt_accum_download", "rt_aov_download", "rt_stats", "rt_stats_reset", "rt_last_dispatch_ms",
+    "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_context", "rt_group_set_option", "rt_group_scene_upload",
+    "rt_group_spheres_upload", "rt_group_textures_upload", "rt_group_models_update", "rt_group_accum_resize", "rt_group_dispatch",
+    "rt_group_dispatch_frames", "rt_group_sync", "rt_group_accum_download", "rt_group_capture_rgb8", "rt_group_stats", "rt_group_stats_reset",
     "rt_host_scene_load", "rt_host_scene_free", "rt_host_scene_vertex_count", "rt_host_scene_index_count",
     "rt_host_scene_model_count", "rt_host_scene_vertices", "rt_host_scene_indices", "rt_host_scene_primitives",
     "rt_host_scene_models", "rt_host_scene_model_name", "rt_host_scene_texture_count", "rt_host_scene_texture",
@@ -168,6 +171,23 @@ def lib():
         L.rt_stats.argtypes = [vp, C.POINTER(RtStats)]
         L.rt_stats_reset.argtypes = [vp]
         L.rt_last_dispatch_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.rt_group_create.argtypes = [C.POINTER(C.c_int), i32, C.POINTER(vp)]
+        L.rt_group_destroy.argtypes = [vp]
+        L.rt_group_size.argtypes = [vp]
+        L.rt_group_context.argtypes = [vp, i32, C.POINTER(vp)]
+        L.rt_group_set_option.argtypes = [vp, i32, C.c_int64]
+        L.rt_group_scene_upload.argtypes = [vp, vp, u64, vp, u64, vp, u32, vp, vp, u32]
+        L.rt_group_spheres_upload.argtypes = [vp, vp, u64]
+        L.rt_group_textures_upload.argtypes = [vp, vp, u32]
+        L.rt_group_models_update.argtypes = [vp, vp, u32, vp]
+        L.rt_group_accum_resize.argtypes = [vp, u32, u32]
+        L.rt_group_dispatch.argtypes = [vp, vp]
+        L.rt_group_dispatch_frames.argtypes = [vp, vp, u32]
+        L.rt_group_sync.argtypes = [vp]
+        L.rt_group_accum_download.argtypes = [vp, vp]
+        L.rt_group_capture_rgb8.argtypes = [vp, vp]
+        L.rt_group_stats.argtypes = [vp, C.POINTER(RtStats)]
+        L.rt_group_stats_reset.argtypes = [vp]
         L.rt_host_scene_load.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.rt_host_scene_free.argtypes = [vp]
         L.rt_host_scene_free.restype = None
@@ -418,4 +438,94 @@ class Context:
     def last_dispatch_ms(self):
         ms = C.c_float()
         _check(lib().rt_last_dispatch_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+
+class Group:
+    """One rt_group: n GPUs behind one host object (the scene is built once, every device renders its bands)."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        _check(lib().rt_group_create(ids, len(device_ids), C.byref(h)))
+        self.handle = h
+        self.width = self.height = 0
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().rt_group_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __len__(self):
+        return int(lib().rt_group_size(self.handle))
+
+    def set_option(self, key, value):
+        _check(lib().rt_group_set_option(self.handle, key, int(value)))
+
+    def scene_upload(self, vertices, indices, primitives, models, transforms=None):
+        v = np.ascontiguousarray(vertices)
+        i = np.ascontiguousarray(indices, np.uint32)
+        p = np.ascontiguousarray(primitives)
+        m = np.ascontiguousarray(models)
+        t = None if transforms is None else np.ascontiguousarray(transforms, np.float32)
+        _check(lib().rt_group_scene_upload(self.handle, v.ctypes.data, len(v), i.ctypes.data, len(i), p.ctypes.data, len(p),
+                                           None if t is None else t.ctypes.data, m.ctypes.data, len(m)))
+
+    def spheres_upload(self, spheres):
+        sp = np.ascontiguousarray(spheres)
+        _check(lib().rt_group_spheres_upload(self.handle, sp.ctypes.data, len(sp)))
+
+    def models_update(self, models, transforms=None):
+        m = np.ascontiguousarray(models)
+        t = None if transforms is None else np.ascontiguousarray(transforms, np.float32)
+        _check(lib().rt_group_models_update(self.handle, m.ctypes.data, len(m), None if t is None else t.ctypes.data))
+
+    def accum_resize(self, w, h):
+        _check(lib().rt_group_accum_resize(self.handle, w, h))
+        self.width, self.height = w, h
+
+    def dispatch(self, uniform):
+        u = np.ascontiguousarray(uniform)
+        _check(lib().rt_group_dispatch(self.handle, u.ctypes.data))
+
+    def dispatch_frames(self, uniform, n_frames):
+        assert uniform.flags.c_contiguous and uniform.dtype.itemsize == 80
+        _check(lib().rt_group_dispatch_frames(self.handle, uniform.ctypes.data, n_frames))
+
+    def sync(self):
+        _check(lib().rt_group_sync(self.handle))
+
+    def accum_download(self):
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        _check(lib().rt_group_accum_download(self.handle, out.ctypes.data))
+        return out
+
+    def capture_rgb8(self):
+        out = np.zeros((self.height, self.width, 3), np.uint8)
+        _check(lib().rt_group_capture_rgb8(self.handle, out.ctypes.data))
+        return out
+
+    def stats(self):
+        s = RtStats()
+        _check(lib().rt_group_stats(self.handle, C.byref(s)))
+        return s
+
+    def stats_reset(self):
+        _check(lib().rt_group_stats_reset(self.handle))
+
+    def shard_ms(self, shard):
+        """Device time of shard's last dispatch (rt_last_dispatch_ms on its context)."""
+        h = C.c_void_p()
+        _check(lib().rt_group_context(self.handle, shard, C.byref(h)))
+        ms = C.c_float()
+        _check(lib().rt_last_dispatch_ms(h, C.byref(ms)))
         return float(ms.value)

@@ -14,6 +14,7 @@
 #include <atomic>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
 #include <thread>
 #include <algorithm>
@@ -28,6 +29,7 @@
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
 int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, bool q8);
 hipError_t rt_launch_capture(const float *accum, uint8_t *rgb, size_t n_pixels, hipStream_t stream);
+hipError_t rt_launch_deinterleave(const float *gathered, float *image, const RtGatherLayout &L, hipStream_t stream);
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
                            RtRefitBox *root_out, bool q8, hipStream_t stream);
@@ -71,19 +73,26 @@ static __device__ __align__(256) unsigned char scratch[RT_STATIC_HEADER_BYTES + 
 #define RT_MAX_DEVICES 64
 static void *g_scratch_ptr[RT_MAX_DEVICES];        // per device: address of `scratch` there, null until rt_create ran on it
 
-struct rt_context {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-    // host copy of the scene inputs (models_update rebuilds from them)
+// Host copy of the scene inputs (rt_models_update rebuilds from them) and the host BVH.  One per context, or ONE shared
+// by all the contexts of an rt_group: the scene is loaded, built and repacked once, however many GPUs render it.
+struct SceneHost {
     std::vector<RtVertex> vertices;
     std::vector<uint32_t> indices;
     std::vector<RtGeometryPrimitive> primitives;
     std::vector<float> transforms;   // n_primitives x 12, row-major 3x4
     std::vector<RtGpuModel> models;
     std::vector<RtSphere> spheres;   // build-defined primitive (BASELINE config C4)
+    rt_host::Bvh2 bvh;               // kept for host refits (rt_models_update)
+    uint64_t bvh_prims = 0;
+};
+
+struct rt_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    std::shared_ptr<SceneHost> hs = std::make_shared<SceneHost>();
     uint32_t n_textures = 0;
     DevTexture *d_textures = nullptr;
     uint32_t *d_texels = nullptr;
@@ -98,15 +107,14 @@ struct rt_context {
     uint32_t stack_entries = 1;
     float scene_abs[3] = {0.0f, 0.0f, 0.0f};
     bool have_scene = false;
+    bool last_update_on_device = false;   // rt_models_update: the last call was served by device_refit alone
     bool models_committed = false;   // the last build_and_upload / device_refit got as far as changing device state
-    rt_host::Bvh2 bvh;               // kept for host refits (rt_models_update)
     // device refit (RT_OPT_REFIT = 2): topology + scratch, uploaded with the scene
     int32_t *d_parent = nullptr;     // per node: parent * 2 + child slot, root -1
     unsigned int *d_arrived = nullptr;
     RtRefitBox *d_cbox = nullptr, *d_tribox = nullptr, *d_root = nullptr;
     float *d_xform = nullptr;        // n_geometries x 12
     uint32_t node_stride = RT_NODE_CHUNKS;
-    uint64_t bvh_prims = 0;
     uint64_t refits = 0, rebuilds = 0;
     double build_seconds = 0.0;
 
@@ -214,7 +222,7 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         DevTri &t = out.tris[slot];
         if (gid >= n_real_tris) {
             const uint32_t si = (uint32_t)(gid - n_real_tris);
-            const RtSphere &sp = ctx.spheres[si];
+            const RtSphere &sp = ctx.hs->spheres[si];
             t.ax = sp.center[0]; t.ay = sp.center[1]; t.az = sp.center[2];
             t.e1x = sp.radius;
             t.gid = gid;
@@ -235,19 +243,19 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         // shading attributes come from the MODEL's ranges (main.wgsl:86-91),
         // untransformed (object_to_world is the identity instance transform)
         const uint32_t g = ids[2 * (size_t)gid], p = ids[2 * (size_t)gid + 1];
-        const RtGpuModel &m = ctx.models[g];
+        const RtGpuModel &m = ctx.hs->models[g];
         const uint32_t is = m.index_start + p * 3u;
         const RtVertex *v[3];
-        for (int j = 0; j < 3; j++) v[j] = &ctx.vertices[m.vertex_start + ctx.indices[is + j]];
+        for (int j = 0; j < 3; j++) v[j] = &ctx.hs->vertices[m.vertex_start + ctx.hs->indices[is + j]];
         DevShade &s = out.shade[slot];
         memcpy(s.p0, v[0]->position, 12); s.n0x = v[0]->normal[0]; s.n0y = v[0]->normal[1]; s.n0z = v[0]->normal[2]; memcpy(s.uv0, v[0]->uv, 8);
         memcpy(s.p1, v[1]->position, 12); memcpy(s.n1, v[1]->normal, 12); memcpy(s.uv1, v[1]->uv, 8);
         memcpy(s.p2, v[2]->position, 12); memcpy(s.n2, v[2]->normal, 12); memcpy(s.uv2, v[2]->uv, 8);
         s.geometry = g;
         s.primitive = p;
-        const RtGeometryPrimitive &gp = ctx.primitives[g];
+        const RtGeometryPrimitive &gp = ctx.hs->primitives[g];
         for (int j = 0; j < 3; j++)
-            if (memcmp(ctx.vertices[gp.first_vertex + ctx.indices[gp.first_index + 3u * p + j]].position, v[j]->position, 12) != 0)
+            if (memcmp(ctx.hs->vertices[gp.first_vertex + ctx.hs->indices[gp.first_index + 3u * p + j]].position, v[j]->position, 12) != 0)
                 sources_agree.store(false, std::memory_order_relaxed);
     }
     };
@@ -316,10 +324,10 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
 
 // models[] → the material records the kernel reads (main.wgsl:53-68)
 void convert_materials(const rt_context &ctx, std::vector<DevMaterial> &mats) {
-    mats.assign(ctx.models.size() ? ctx.models.size() : 1, DevMaterial());
+    mats.assign(ctx.hs->models.size() ? ctx.hs->models.size() : 1, DevMaterial());
     memset(mats.data(), 0, mats.size() * sizeof(DevMaterial));
-    for (size_t i = 0; i < ctx.models.size(); i++) {
-        const RtMaterial &m = ctx.models[i].material;
+    for (size_t i = 0; i < ctx.hs->models.size(); i++) {
+        const RtMaterial &m = ctx.hs->models[i].material;
         DevMaterial &d = mats[i];
         memcpy(d.diffuse, m.metal.diffuse_color, 12);
         memcpy(d.specular, m.metal.specular_color, 12);
@@ -333,29 +341,39 @@ void convert_materials(const rt_context &ctx, std::vector<DevMaterial> &mats) {
     }
 }
 
-int build_and_upload(rt_context *ctx, bool allow_refit = false) {
+// What the host half of a scene build hands to the device half: built once, uploaded to one GPU or to every GPU of a group.
+struct Built {
+    Repacked rp;
+    std::vector<DevMaterial> mats;
+    std::vector<uint8_t> packed_nodes;   // the node array as it is uploaded (restrided when node_stride != RT_NODE_CHUNKS)
+    uint64_t n_prims = 0;
+    double build_seconds = 0.0;
+};
+
+// Host half: validate, gather triangles, build (or refit) the BVH2 in ctx->hs, repack it.  Touches no device state.
+int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     ctx->models_committed = false;
     std::string err;
     std::vector<float> corners;
     std::vector<uint32_t> ids;
-    if (!rt_host::gather_triangles(ctx->vertices.data(), ctx->vertices.size(), ctx->indices.data(), ctx->indices.size(),
-                                   ctx->primitives.data(), (uint32_t)ctx->primitives.size(),
-                                   ctx->transforms.empty() ? nullptr : ctx->transforms.data(), corners, ids, err))
+    if (!rt_host::gather_triangles(ctx->hs->vertices.data(), ctx->hs->vertices.size(), ctx->hs->indices.data(), ctx->hs->indices.size(),
+                                   ctx->hs->primitives.data(), (uint32_t)ctx->hs->primitives.size(),
+                                   ctx->hs->transforms.empty() ? nullptr : ctx->hs->transforms.data(), corners, ids, err))
         return fail(RT_ERR_INVALID_ARGUMENT, "scene: %s", err.c_str());
     const uint64_t n_tris = ids.size() / 2;
     // models[] is indexed by geometry_index (main.wgsl:86)
-    if (ctx->models.size() < ctx->primitives.size())
-        return fail(RT_ERR_INVALID_ARGUMENT, "scene: %zu models for %zu geometries", ctx->models.size(), ctx->primitives.size());
+    if (ctx->hs->models.size() < ctx->hs->primitives.size())
+        return fail(RT_ERR_INVALID_ARGUMENT, "scene: %zu models for %zu geometries", ctx->hs->models.size(), ctx->hs->primitives.size());
     for (uint64_t t = 0; t < n_tris; t++) {
-        const RtGpuModel &m = ctx->models[ids[2 * t]];
+        const RtGpuModel &m = ctx->hs->models[ids[2 * t]];
         uint64_t is = (uint64_t)m.index_start + 3ull * ids[2 * t + 1];
-        if (is + 3 > ctx->indices.size())
+        if (is + 3 > ctx->hs->indices.size())
             return fail(RT_ERR_INVALID_ARGUMENT, "scene: model index range exceeds the index buffer");
         for (int j = 0; j < 3; j++)
-            if ((uint64_t)m.vertex_start + ctx->indices[is + j] >= ctx->vertices.size())
+            if ((uint64_t)m.vertex_start + ctx->hs->indices[is + j] >= ctx->hs->vertices.size())
                 return fail(RT_ERR_INVALID_ARGUMENT, "scene: model vertex range exceeds the vertex buffer");
     }
-    const uint64_t n_prims = n_tris + ctx->spheres.size();
+    const uint64_t n_prims = n_tris + ctx->hs->spheres.size();
     if (n_prims >= (1ull << 28)) return fail(RT_ERR_INVALID_ARGUMENT, "scene: more than 2^28 primitives");
     std::vector<rt_host::Aabb> boxes(n_prims);
     for (uint64_t t = 0; t < n_tris; t++) {
@@ -365,15 +383,15 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
             boxes[t].hi[k] = fmaxf(c[k], fmaxf(c[3 + k], c[6 + k]));
         }
     }
-    for (uint64_t i = 0; i < ctx->spheres.size(); i++) {
-        const RtSphere &sp = ctx->spheres[i];
+    for (uint64_t i = 0; i < ctx->hs->spheres.size(); i++) {
+        const RtSphere &sp = ctx->hs->spheres[i];
         if (!(sp.radius > 0.0f)) return fail(RT_ERR_INVALID_ARGUMENT, "sphere %llu: radius must be positive", (unsigned long long)i);
-        if (sp.model >= ctx->models.size()) return fail(RT_ERR_INVALID_ARGUMENT, "sphere %llu: model index out of range", (unsigned long long)i);
+        if (sp.model >= ctx->hs->models.size()) return fail(RT_ERR_INVALID_ARGUMENT, "sphere %llu: model index out of range", (unsigned long long)i);
         const float r = sp.radius * 1.0001f + 1e-6f;   // the quadratic's roots are not exact
         for (int k = 0; k < 3; k++) { boxes[n_tris + i].lo[k] = sp.center[k] - r; boxes[n_tris + i].hi[k] = sp.center[k] + r; }
     }
-    rt_host::Bvh2 &bvh = ctx->bvh;
-    if (allow_refit && ctx->opt_refit != 0 && ctx->bvh_prims == n_prims && n_prims > 0) {
+    rt_host::Bvh2 &bvh = ctx->hs->bvh;
+    if (allow_refit && ctx->opt_refit != 0 && ctx->hs->bvh_prims == n_prims && n_prims > 0) {
         // ≙ acceleration_structure.update(), src/app.rs:61: same primitives, moved
         rt_host::refit_bvh2(boxes.data(), bvh);
         ctx->refits++;
@@ -384,11 +402,11 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
         opt.traversal_cost = ctx->sah_traversal_cost;
         if (ctx->bvh_max_depth > 0) opt.max_depth = ctx->bvh_max_depth;
         rt_host::build_bvh2(boxes.data(), n_prims, opt, bvh);
-        ctx->bvh_prims = n_prims;
+        ctx->hs->bvh_prims = n_prims;
         ctx->rebuilds++;
     }
     if (bvh.nodes.size() * 4ull >= (1ull << 31)) return fail(RT_ERR_INVALID_ARGUMENT, "scene: BVH has too many nodes");
-    Repacked rp;
+    Repacked &rp = out.rp;
     // Node stride: 48 B (default) packs the tree tightest; 64 B keeps every node inside one 64-B memory sector.
     // Measured: 48 B is 1.5 % faster on C3 (cache-resident), no difference on C4 (2 GB of records).
     rp.node_stride = ctx->opt_node_stride ? (uint32_t)ctx->opt_node_stride : (uint32_t)RT_NODE_CHUNKS;
@@ -400,10 +418,25 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
         if (rp.q8) rp.node_stride = 2;
     }
     repack(bvh, corners, ids, *ctx, rp);
-    ctx->build_seconds = bvh.build_seconds;
-    std::vector<DevMaterial> mats;
-    convert_materials(*ctx, mats);
+    out.build_seconds = bvh.build_seconds;
+    out.n_prims = n_prims;
+    convert_materials(*ctx, out.mats);
+    if (rp.node_stride != RT_NODE_CHUNKS) {
+        // other strides (64-byte slots, 32-byte q8 records = the first 32 bytes of a DevNode): restride on the host and
+        // upload in one piece (a pitched copy of 10^8 32-byte rows takes minutes)
+        const size_t pitch = (size_t)rp.node_stride * 16u, row = pitch < sizeof(DevNode) ? pitch : sizeof(DevNode);
+        out.packed_nodes.assign(rp.nodes.size() * pitch ? rp.nodes.size() * pitch : 1, 0);
+        for (size_t i = 0; i < rp.nodes.size(); i++) memcpy(out.packed_nodes.data() + i * pitch, &rp.nodes[i], row);
+    }
+    return RT_OK;
+}
 
+// Device half: replace the context's device scene with `b`.
+int device_upload(rt_context *ctx, const Built &b) {
+    const Repacked &rp = b.rp;
+    const std::vector<DevMaterial> &mats = b.mats;
+    const uint64_t n_prims = b.n_prims;
+    ctx->build_seconds = b.build_seconds;
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     ctx->models_committed = true;    // from here on the device scene is being replaced
@@ -415,16 +448,8 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     RT_HIP(hipMalloc((void **)&ctx->d_shade, rp.shade.size() * sizeof(DevShade)));
     RT_HIP(hipMalloc((void **)&ctx->d_materials, mats.size() * sizeof(DevMaterial)));
     ctx->materials_capacity = mats.size();
-    if (rp.node_stride == RT_NODE_CHUNKS) {
-        RT_HIP(hipMemcpy(ctx->d_nodes, rp.nodes.data(), node_bytes, hipMemcpyHostToDevice));
-    } else {
-        // other strides (64-byte slots, 32-byte q8 records = the first 32 bytes of a DevNode): restride on the host and
-        // upload in one piece (a pitched copy of 10^8 32-byte rows takes minutes)
-        const size_t pitch = (size_t)rp.node_stride * 16u, row = pitch < sizeof(DevNode) ? pitch : sizeof(DevNode);
-        std::vector<uint8_t> packed(node_bytes ? node_bytes : 1, 0);
-        for (size_t i = 0; i < rp.nodes.size(); i++) memcpy(packed.data() + i * pitch, &rp.nodes[i], row);
-        RT_HIP(hipMemcpy(ctx->d_nodes, packed.data(), node_bytes, hipMemcpyHostToDevice));
-    }
+    RT_HIP(hipMemcpy(ctx->d_nodes, rp.node_stride == RT_NODE_CHUNKS ? (const void *)rp.nodes.data() : (const void *)b.packed_nodes.data(),
+                     node_bytes, hipMemcpyHostToDevice));
     ctx->node_bytes = node_bytes;
     ctx->node_stride = rp.node_stride;
     ctx->node_q8 = rp.q8;
@@ -436,7 +461,7 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
         RT_HIP(hipMalloc((void **)&ctx->d_cbox, 2 * nn * sizeof(RtRefitBox)));
         RT_HIP(hipMalloc((void **)&ctx->d_tribox, rp.tris.size() * sizeof(RtRefitBox)));
         RT_HIP(hipMalloc((void **)&ctx->d_root, sizeof(RtRefitBox)));
-        RT_HIP(hipMalloc((void **)&ctx->d_xform, (ctx->primitives.size() ? ctx->primitives.size() : 1) * 12 * sizeof(float)));
+        RT_HIP(hipMalloc((void **)&ctx->d_xform, (ctx->hs->primitives.size() ? ctx->hs->primitives.size() : 1) * 12 * sizeof(float)));
         RT_HIP(hipMemcpy(ctx->d_parent, rp.parent.data(), nn * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     RT_HIP(hipMemcpy(ctx->d_tris, rp.tris.data(), rp.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
@@ -449,6 +474,12 @@ int build_and_upload(rt_context *ctx, bool allow_refit = false) {
     ctx->persistent_blocks = 0;
     ctx->have_scene = true;
     return RT_OK;
+}
+
+int build_and_upload(rt_context *ctx, bool allow_refit = false) {
+    Built b;
+    int r = host_build(ctx, allow_refit, b);
+    return r ? r : device_upload(ctx, b);
 }
 
 int setup_accum(rt_context *ctx, uint32_t w, uint32_t h) {
@@ -555,7 +586,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
     P.chunk = ctx->chunk ? ctx->chunk : ((uint64_t)P.tiles_x * P.local_bands * 64u >= (6u << 20) ? 128u : 64u);
     if (ctx->opt_kernel != 1) {
         RT_HIP(hipMemsetAsync(P.queue, 0, sizeof(DevQueue), ctx->stream));     // the head must start at zero, whatever the last call left
-        const bool ext = !ctx->spheres.empty() || ctx->n_textures > 0;
+        const bool ext = !ctx->hs->spheres.empty() || ctx->n_textures > 0;
         const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
         const int sel = (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
         if (ctx->persistent_blocks == 0 || ctx->persistent_sel != sel) {
@@ -572,7 +603,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
         RT_HIP(hipMemsetAsync(P.probe, 0, probe_waves * 24, ctx->stream));
     }
 #endif
-    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->spheres.empty() || ctx->n_textures > 0, ctx->persistent_blocks, ctx->stream));
+    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->hs->spheres.empty() || ctx->n_textures > 0, ctx->persistent_blocks, ctx->stream));
 #ifdef RT_TAIL_PROBE
     if (P.probe) {
         std::vector<unsigned long long> pr(3 * probe_waves), ends;
@@ -626,10 +657,10 @@ int device_refit(rt_context *ctx) {
     RT_HIP(hipMemcpyAsync(ctx->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice, ctx->stream));
     const float *xform = nullptr;
     std::vector<float> resolved;
-    if (!ctx->transforms.empty()) {
-        resolved.resize(12 * ctx->primitives.size());
-        for (size_t g = 0; g < ctx->primitives.size(); g++)      // src/scene.rs:141-147: a geometry names its transform by offset
-            memcpy(&resolved[12 * g], &ctx->transforms[12 * ctx->primitives[g].transformation_offset], 48);
+    if (!ctx->hs->transforms.empty()) {
+        resolved.resize(12 * ctx->hs->primitives.size());
+        for (size_t g = 0; g < ctx->hs->primitives.size(); g++)      // src/scene.rs:141-147: a geometry names its transform by offset
+            memcpy(&resolved[12 * g], &ctx->hs->transforms[12 * ctx->hs->primitives[g].transformation_offset], 48);
         RT_HIP(hipMemcpyAsync(ctx->d_xform, resolved.data(), resolved.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         xform = ctx->d_xform;
     }
@@ -762,13 +793,13 @@ int rt_scene_upload(rt_context *ctx, const RtVertex *vertices, uint64_t n_vertic
     for (uint32_t g = 0; g < n_primitives; g++)
         if (transforms && primitives[g].transformation_offset >= n_primitives)
             return fail(RT_ERR_INVALID_ARGUMENT, "geometry %u: transformation_offset out of range", g);
-    ctx->vertices.assign(vertices, vertices + n_vertices);
-    ctx->indices.assign(indices, indices + n_indices);
-    ctx->primitives.assign(primitives, primitives + n_primitives);
-    ctx->models.assign(models, models + n_models);
-    if (transforms) ctx->transforms.assign(transforms, transforms + 12ull * n_primitives);
-    else ctx->transforms.clear();
-    ctx->spheres.clear();
+    ctx->hs->vertices.assign(vertices, vertices + n_vertices);
+    ctx->hs->indices.assign(indices, indices + n_indices);
+    ctx->hs->primitives.assign(primitives, primitives + n_primitives);
+    ctx->hs->models.assign(models, models + n_models);
+    if (transforms) ctx->hs->transforms.assign(transforms, transforms + 12ull * n_primitives);
+    else ctx->hs->transforms.clear();
+    ctx->hs->spheres.clear();
     ctx->n_textures = 0;
     ctx->have_scene = false;
     return build_and_upload(ctx);
@@ -777,7 +808,7 @@ int rt_scene_upload(rt_context *ctx, const RtVertex *vertices, uint64_t n_vertic
 int rt_spheres_upload(rt_context *ctx, const RtSphere *spheres, uint64_t n_spheres) {
     if (!ctx || (n_spheres && !spheres)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_spheres_upload before rt_scene_upload");
-    ctx->spheres.assign(spheres, spheres + n_spheres);
+    ctx->hs->spheres.assign(spheres, spheres + n_spheres);
     return build_and_upload(ctx);
 }
 
@@ -817,35 +848,39 @@ int rt_textures_upload(rt_context *ctx, const RtTexture *textures, uint32_t n_te
 int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models, const float *transforms) {
     if (!ctx || (n_models && !models)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_models_update before rt_scene_upload");
-    if (n_models < ctx->primitives.size())
-        return fail(RT_ERR_INVALID_ARGUMENT, "scene: %u models for %zu geometries", n_models, ctx->primitives.size());
+    if (n_models < ctx->hs->primitives.size())
+        return fail(RT_ERR_INVALID_ARGUMENT, "scene: %u models for %zu geometries", n_models, ctx->hs->primitives.size());
     if (transforms)
-        for (size_t g = 0; g < ctx->primitives.size(); g++)
-            if (ctx->primitives[g].transformation_offset >= ctx->primitives.size())
+        for (size_t g = 0; g < ctx->hs->primitives.size(); g++)
+            if (ctx->hs->primitives[g].transformation_offset >= ctx->hs->primitives.size())
                 return fail(RT_ERR_INVALID_ARGUMENT, "geometry %zu: transformation_offset out of range", g);
     // The device refit re-derives triangles from the shading records baked at upload, which took their vertices from the
     // models' vertex_start / index_start (main.wgsl:86-91): it is only valid while those ranges are what was uploaded.
-    bool ranges_kept = n_models >= ctx->models.size();
-    for (size_t g = 0; g < ctx->models.size() && ranges_kept; g++)
-        ranges_kept = models[g].vertex_start == ctx->models[g].vertex_start && models[g].index_start == ctx->models[g].index_start;
+    bool ranges_kept = n_models >= ctx->hs->models.size();
+    for (size_t g = 0; g < ctx->hs->models.size() && ranges_kept; g++)
+        ranges_kept = models[g].vertex_start == ctx->hs->models[g].vertex_start && models[g].index_start == ctx->hs->models[g].index_start;
     bool spheres_ok = true;
-    for (const RtSphere &sp : ctx->spheres) spheres_ok = spheres_ok && sp.model < n_models;
+    for (const RtSphere &sp : ctx->hs->spheres) spheres_ok = spheres_ok && sp.model < n_models;
     // commit the new models / transforms only once the path taken has accepted them
     std::vector<RtGpuModel> old_models(models, models + n_models);
     std::vector<float> old_transforms;
-    old_models.swap(ctx->models);
+    old_models.swap(ctx->hs->models);
     if (transforms) {
-        old_transforms.assign(transforms, transforms + 12ull * ctx->primitives.size());
-        old_transforms.swap(ctx->transforms);
+        old_transforms.assign(transforms, transforms + 12ull * ctx->hs->primitives.size());
+        old_transforms.swap(ctx->hs->transforms);
     }
     int r;
     // device refit: same primitives, same tree, same model ranges, the sphere -> model references still valid and the
     // material array as uploaded has room for the new models
-    if (ctx->opt_refit == 2 && ctx->d_parent && ctx->n_nodes > 1 && ranges_kept && spheres_ok && n_models <= ctx->materials_capacity) r = device_refit(ctx);
-    else r = build_and_upload(ctx, /*allow_refit=*/true);
+    ctx->last_update_on_device = false;
+    if (ctx->opt_refit == 2 && ctx->d_parent && ctx->n_nodes > 1 && ranges_kept && spheres_ok && n_models <= ctx->materials_capacity) {
+        const uint64_t rebuilds_before = ctx->rebuilds, refits_before = ctx->refits;
+        r = device_refit(ctx);
+        ctx->last_update_on_device = r == RT_OK && ctx->rebuilds == rebuilds_before && ctx->refits == refits_before + 1;
+    } else r = build_and_upload(ctx, /*allow_refit=*/true);
     if (r != RT_OK && !ctx->models_committed) {       // rejected before anything reached the device: the old scene stays in force
-        old_models.swap(ctx->models);
-        if (transforms) old_transforms.swap(ctx->transforms);
+        old_models.swap(ctx->hs->models);
+        if (transforms) old_transforms.swap(ctx->hs->transforms);
     }
     return r;
 }
@@ -1114,6 +1149,297 @@ int rt_host_scene_finish(const rt_host_scene *s, rt_context *ctx) {
         tex[i].height = sc.textures[i].height;
     }
     return rt_textures_upload(ctx, tex.data(), (uint32_t)tex.size());
+}
+
+}  // extern "C"
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// rt_group: one host object that owns n GPUs (SURVEY §8(b) `create(device_ids[], n)`; the reference's single context
+// owning all resources, src/main.rs:27-59).  The scene is validated, built and repacked ONCE and uploaded to every
+// device; each device renders its bands (rt_set_shard) on its own stream; downloads gather the bands on the first
+// device (peer copies over xGMI) and de-interleave them there.  Everything is driven from one host thread; launches
+// are asynchronous, so the devices render concurrently.
+struct rt_group {
+    std::vector<rt_context *> ctx;
+    std::vector<hipEvent_t> done;      // per shard: its stream's work up to the gather
+    float *d_gather = nullptr;         // on ctx[0]'s device: all shards' packed rows, one shard after the other
+    float *d_image = nullptr;          // on ctx[0]'s device: the de-interleaved image
+    uint64_t image_elems = 0;
+    uint32_t width = 0, height = 0;
+};
+
+namespace {
+
+// the full image, de-interleaved, in g->d_image on the first device (or that device's own buffer when there is one shard)
+int group_gather(rt_group *g, const float **image) {
+    rt_context *c0 = g->ctx[0];
+    const size_t n = g->ctx.size();
+    if (!c0->d_accum) return fail(RT_ERR_NO_ACCUM, "no accumulation buffer");
+    if (n == 1) { *image = c0->d_accum; return RT_OK; }
+    RtGatherLayout L;
+    memset(&L, 0, sizeof L);
+    L.width = g->width; L.height = g->height; L.n_shards = (uint32_t)n;
+    uint32_t row = 0;
+    for (size_t i = 0; i < n; i++) {
+        L.first_row[i] = row;
+        row += (uint32_t)local_rows_for(g->height, (uint32_t)i, (uint32_t)n);
+    }
+    for (size_t i = 1; i < n; i++) {
+        RT_HIP(hipSetDevice(g->ctx[i]->device));
+        RT_HIP(hipEventRecord(g->done[i], g->ctx[i]->stream));
+    }
+    RT_HIP(hipSetDevice(c0->device));
+    for (size_t i = 0; i < n; i++) {
+        rt_context *c = g->ctx[i];
+        const size_t bytes = (size_t)local_rows_for(g->height, (uint32_t)i, (uint32_t)n) * g->width * RT_ACCUM_STRIDE_BYTES;
+        if (bytes == 0) continue;
+        if (i) RT_HIP(hipStreamWaitEvent(c0->stream, g->done[i], 0));
+        float *dst = g->d_gather + (size_t)L.first_row[i] * g->width * 4u;
+        if (c->device == c0->device) RT_HIP(hipMemcpyAsync(dst, c->d_accum, bytes, hipMemcpyDeviceToDevice, c0->stream));
+        else RT_HIP(hipMemcpyPeerAsync(dst, c0->device, c->d_accum, c->device, bytes, c0->stream));
+    }
+    RT_HIP(rt_launch_deinterleave(g->d_gather, g->d_image, L, c0->stream));
+    *image = g->d_image;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_group_create(const int *device_ids, int n_devices, rt_group **out) {
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > RT_GROUP_MAX) return fail(RT_ERR_INVALID_ARGUMENT, "1..%d devices", RT_GROUP_MAX);
+    rt_group *g = new rt_group();
+    for (int i = 0; i < n_devices; i++) {
+        rt_context *c = nullptr;
+        hipEvent_t ev = nullptr;
+        int r = rt_create(device_ids[i], &c);
+        if (r == RT_OK && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) r = fail(RT_ERR_HIP, "hipEventCreate failed");
+        if (r == RT_OK) r = rt_set_shard(c, (uint32_t)i, (uint32_t)n_devices);
+        if (r != RT_OK) {
+            const std::string keep = g_last_error;
+            if (ev) (void)hipEventDestroy(ev);
+            if (c) rt_destroy(c);
+            rt_group_destroy(g);
+            g_last_error = keep;
+            return r;
+        }
+        if (i) c->hs = g->ctx[0]->hs;              // ONE host copy of the scene and ONE host BVH for the whole group
+        g->ctx.push_back(c);
+        g->done.push_back(ev);
+    }
+    // peer access lets the gather's copies go GPU to GPU over xGMI; without it HIP stages them through the host
+    for (int i = 1; i < n_devices; i++) {
+        if (device_ids[i] == device_ids[0]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) {
+            (void)hipSetDevice(device_ids[0]);
+            (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
+            (void)hipGetLastError();               // "already enabled" is fine
+        }
+    }
+    *out = g;
+    return RT_OK;
+}
+
+int rt_group_destroy(rt_group *g) {
+    if (!g) return RT_OK;
+    if (!g->ctx.empty()) {
+        (void)hipSetDevice(g->ctx[0]->device);
+        if (g->ctx[0]->stream) (void)hipStreamSynchronize(g->ctx[0]->stream);
+        dev_free(g->d_gather); dev_free(g->d_image);
+    }
+    for (size_t i = 0; i < g->ctx.size(); i++) {
+        (void)hipSetDevice(g->ctx[i]->device);
+        if (g->done[i]) (void)hipEventDestroy(g->done[i]);
+        rt_destroy(g->ctx[i]);
+    }
+    delete g;
+    return RT_OK;
+}
+
+int rt_group_size(const rt_group *g) { return g ? (int)g->ctx.size() : 0; }
+
+int rt_group_context(rt_group *g, int shard, rt_context **out) {
+    if (!g || !out || shard < 0 || shard >= (int)g->ctx.size()) return fail(RT_ERR_INVALID_ARGUMENT, "shard out of range");
+    *out = g->ctx[(size_t)shard];
+    return RT_OK;
+}
+
+int rt_group_set_option(rt_group *g, int key, int64_t value) {
+    if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
+    for (rt_context *c : g->ctx) { int r = rt_set_option(c, key, value); if (r) return r; }
+    return RT_OK;
+}
+
+int rt_group_scene_upload(rt_group *g, const RtVertex *vertices, uint64_t n_vertices, const uint32_t *indices, uint64_t n_indices,
+                          const RtGeometryPrimitive *primitives, uint32_t n_primitives, const float *transforms,
+                          const RtGpuModel *models, uint32_t n_models) {
+    if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
+    if ((n_vertices && !vertices) || (n_indices && !indices) || (n_primitives && !primitives) || (n_models && !models))
+        return fail(RT_ERR_INVALID_ARGUMENT, "null array with non-zero count");
+    for (uint32_t p = 0; p < n_primitives; p++)
+        if (transforms && primitives[p].transformation_offset >= n_primitives)
+            return fail(RT_ERR_INVALID_ARGUMENT, "geometry %u: transformation_offset out of range", p);
+    SceneHost &hs = *g->ctx[0]->hs;
+    hs.vertices.assign(vertices, vertices + n_vertices);
+    hs.indices.assign(indices, indices + n_indices);
+    hs.primitives.assign(primitives, primitives + n_primitives);
+    hs.models.assign(models, models + n_models);
+    if (transforms) hs.transforms.assign(transforms, transforms + 12ull * n_primitives);
+    else hs.transforms.clear();
+    hs.spheres.clear();
+    Built b;
+    for (rt_context *c : g->ctx) { c->n_textures = 0; c->have_scene = false; }
+    int r = host_build(g->ctx[0], false, b);                 // once
+    for (size_t i = 0; i < g->ctx.size() && r == RT_OK; i++) r = device_upload(g->ctx[i], b);   // n times
+    return r;
+}
+
+int rt_group_spheres_upload(rt_group *g, const RtSphere *spheres, uint64_t n_spheres) {
+    if (!g || (n_spheres && !spheres)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (!g->ctx[0]->have_scene) return fail(RT_ERR_NO_SCENE, "rt_group_spheres_upload before rt_group_scene_upload");
+    g->ctx[0]->hs->spheres.assign(spheres, spheres + n_spheres);
+    Built b;
+    int r = host_build(g->ctx[0], false, b);
+    for (size_t i = 0; i < g->ctx.size() && r == RT_OK; i++) r = device_upload(g->ctx[i], b);
+    return r;
+}
+
+int rt_group_textures_upload(rt_group *g, const RtTexture *textures, uint32_t n_textures) {
+    if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
+    for (rt_context *c : g->ctx) { int r = rt_textures_upload(c, textures, n_textures); if (r) return r; }
+    return RT_OK;
+}
+
+int rt_group_models_update(rt_group *g, const RtGpuModel *models, uint32_t n_models, const float *transforms) {
+    if (!g || (n_models && !models)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    rt_context *c0 = g->ctx[0];
+    if (!c0->have_scene) return fail(RT_ERR_NO_SCENE, "rt_group_models_update before rt_group_scene_upload");
+    // the first context takes the update exactly as rt_models_update does (it validates, and commits the shared host copy);
+    // the others then follow the path it took: a refit on their own device, or the upload of what the host rebuilt
+    const uint64_t refits_before = c0->refits;
+    const bool device_path_possible = c0->opt_refit == 2 && c0->d_parent != nullptr;
+    int r = rt_models_update(c0, models, n_models, transforms);
+    if (r) return r;
+    const bool refitted_on_device = device_path_possible && c0->refits == refits_before + 1 && c0->last_update_on_device;
+    if (g->ctx.size() == 1) return RT_OK;
+    if (refitted_on_device) {
+        for (size_t i = 1; i < g->ctx.size() && r == RT_OK; i++) r = device_refit(g->ctx[i]);
+        return r;
+    }
+    Built b;
+    r = host_build(c0, /*allow_refit=*/true, b);             // same inputs, same tree: one more host pass, shared by the other devices
+    for (size_t i = 1; i < g->ctx.size() && r == RT_OK; i++) r = device_upload(g->ctx[i], b);
+    return r;
+}
+
+int rt_group_accum_resize(rt_group *g, uint32_t w, uint32_t h) {
+    if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
+    for (rt_context *c : g->ctx) { int r = rt_accum_resize(c, w, h); if (r) return r; }
+    g->width = w; g->height = h;
+    if (g->ctx.size() > 1) {
+        rt_context *c0 = g->ctx[0];
+        RT_HIP(hipSetDevice(c0->device));
+        RT_HIP(hipStreamSynchronize(c0->stream));
+        const uint64_t elems = ((uint64_t)w * h ? (uint64_t)w * h : 1) * 4u;
+        if (elems > g->image_elems) {
+            dev_free(g->d_gather); dev_free(g->d_image);
+            g->image_elems = 0;
+            RT_HIP(hipMalloc((void **)&g->d_gather, elems * sizeof(float)));
+            RT_HIP(hipMalloc((void **)&g->d_image, elems * sizeof(float)));
+            g->image_elems = elems;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_group_dispatch(rt_group *g, const RtUniform *uniform) {
+    if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
+    for (rt_context *c : g->ctx) { int r = rt_dispatch(c, uniform); if (r) return r; }
+    return RT_OK;
+}
+
+int rt_group_dispatch_frames(rt_group *g, RtUniform *uniform, uint32_t n_frames) {
+    if (!g || !uniform) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    const RtUniform start = *uniform;
+    RtUniform last = start;
+    for (rt_context *c : g->ctx) {               // every device advances the same frame sequence from the same start
+        RtUniform u = start;
+        int r = rt_dispatch_frames(c, &u, n_frames);
+        if (r) return r;
+        last = u;
+    }
+    *uniform = last;
+    return RT_OK;
+}
+
+int rt_group_sync(rt_group *g) {
+    if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
+    for (rt_context *c : g->ctx) { int r = rt_sync(c); if (r) return r; }
+    return RT_OK;
+}
+
+int rt_group_accum_download(rt_group *g, float *dst) {
+    if (!g || !dst) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    const float *image = nullptr;
+    int r = group_gather(g, &image);
+    if (r) return r;
+    rt_context *c0 = g->ctx[0];
+    RT_HIP(hipSetDevice(c0->device));
+    RT_HIP(hipMemcpyAsync(dst, image, (size_t)g->width * g->height * RT_ACCUM_STRIDE_BYTES, hipMemcpyDeviceToHost, c0->stream));
+    RT_HIP(hipStreamSynchronize(c0->stream));
+    return RT_OK;
+}
+
+int rt_group_capture_rgb8(rt_group *g, uint8_t *dst) {
+    if (!g || !dst) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    const float *image = nullptr;
+    int r = group_gather(g, &image);
+    if (r) return r;
+    rt_context *c0 = g->ctx[0];
+    const uint64_t n_pixels = (uint64_t)g->width * g->height;
+    if (n_pixels == 0) return RT_OK;
+    RT_HIP(hipSetDevice(c0->device));
+    if (c0->rgb_bytes < n_pixels * 3) {
+        RT_HIP(hipStreamSynchronize(c0->stream));
+        dev_free(c0->d_rgb);
+        c0->rgb_bytes = 0;
+        RT_HIP(hipMalloc((void **)&c0->d_rgb, n_pixels * 3));
+        c0->rgb_bytes = n_pixels * 3;
+    }
+    RT_HIP(rt_launch_capture(image, c0->d_rgb, n_pixels, c0->stream));
+    RT_HIP(hipMemcpyAsync(dst, c0->d_rgb, n_pixels * 3, hipMemcpyDeviceToHost, c0->stream));
+    RT_HIP(hipStreamSynchronize(c0->stream));
+    return RT_OK;
+}
+
+int rt_group_stats(rt_group *g, RtStats *out) {
+    if (!g || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    RtStats sum;
+    memset(&sum, 0, sizeof sum);
+    for (size_t i = 0; i < g->ctx.size(); i++) {
+        RtStats s;
+        int r = rt_stats(g->ctx[i], &s);
+        if (r) return r;
+        if (i == 0) sum = s;                     // static figures and host-side counts: the first device's
+        else {
+            sum.rays += s.rays; sum.pixel_frames += s.pixel_frames; sum.node_visits += s.node_visits; sum.triangle_tests += s.triangle_tests;
+            sum.wave_node_iters += s.wave_node_iters; sum.wave_leaf_iters += s.wave_leaf_iters; sum.wave_steps += s.wave_steps;
+            sum.launches += s.launches; sum.guard_trips += s.guard_trips;
+        }
+    }
+    *out = sum;
+    return RT_OK;
+}
+
+int rt_group_stats_reset(rt_group *g) {
+    if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
+    for (rt_context *c : g->ctx) { int r = rt_stats_reset(c); if (r) return r; }
+    return RT_OK;
 }
 
 }  // extern "C"

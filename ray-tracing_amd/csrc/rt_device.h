@@ -94,6 +94,13 @@ struct DevQueue {
     unsigned int pad[3];
 };
 
+// rt_group gather: where each shard's packed rows start in the gathered buffer (in rows)
+#define RT_GROUP_MAX 64
+struct RtGatherLayout {
+    uint32_t width, height, n_shards, pad;
+    uint32_t first_row[RT_GROUP_MAX];
+};
+
 // Material records (64 B each) the phased kernel copies into LDS at its start when the scene has no more than this
 // many: the L1 path is the busiest unit of that kernel and LDS is nearly idle.  Scenes with more read them from memory.
 #define RT_TOP_NODES 64u                 // nodes the host numbers breadth-first at the start of the node array (the levels every ray walks share cache lines)
