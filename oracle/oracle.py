@@ -58,6 +58,8 @@ def lib():
         L.oracle_scene_nodes.argtypes = [C.c_void_p]
         L.oracle_render_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                          C.c_int, C.c_void_p]
+        L.oracle_render_rect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_int, C.c_void_p]
         L.oracle_trace.restype = C.c_int
         L.oracle_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_second_nearest.restype = C.c_float
@@ -134,8 +136,9 @@ class OracleScene:
     def n_nodes(self):
         return lib().oracle_scene_nodes(self.handle)
 
-    def render(self, uniform, accum=None, mode=1, rows=None, want_hits=False):
-        """One dispatch (shaders/main.wgsl:14-33) into `accum` ([H, W, 4] f32, updated in place)."""
+    def render(self, uniform, accum=None, mode=1, rows=None, want_hits=False, cols=None):
+        """One dispatch (shaders/main.wgsl:14-33) into `accum` ([H, W, 4] f32, updated in place); rows / cols restrict it to a
+        rectangle of pixels (the others keep their values)."""
         u = np.ascontiguousarray(uniform)
         W, H = int(u["window"][0][0]), int(u["window"][0][1])
         if accum is None:
@@ -144,8 +147,9 @@ class OracleScene:
         hits = np.full((H, W, 2), 0xFFFFFFFF, np.uint32) if want_hits else None
         cnt = Counters()
         y0, y1 = rows if rows is not None else (0, H)
-        lib().oracle_render_rows(self.handle, u.ctypes.data, accum.ctypes.data,
-                                 None if hits is None else hits.ctypes.data, y0, y1, mode, C.byref(cnt))
+        x0, x1 = cols if cols is not None else (0, W)
+        lib().oracle_render_rect(self.handle, u.ctypes.data, accum.ctypes.data,
+                                 None if hits is None else hits.ctypes.data, x0, x1, y0, y1, mode, C.byref(cnt))
         return accum, hits, cnt
 
     def render_frames(self, uniform, n_frames, mode=1):

@@ -506,10 +506,18 @@ static v3 tone_map(v3 x) {
 /* shaders/main.wgsl:14-33 for rows [y0, y1).  accum = W*H elements of 4 f32
  * (16-B stride, xyz @0); hit_ids = W*H*2 u32 or NULL (primary hit of sample 0).
  * mode 0 = brute force, 1 = BVH. */
+void oracle_render_rect(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids,
+                        uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int mode, OCounters *counters);
 void oracle_render_rows(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids,
                         uint32_t y0, uint32_t y1, int mode, OCounters *counters) {
+    oracle_render_rect(sc, ctx, accum, hit_ids, 0, ctx->window[0], y0, y1, mode, counters);
+}
+/* the same for pixels [x0, x1) x [y0, y1) only (brute-force checks of single pixels in big scenes) */
+void oracle_render_rect(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids,
+                        uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int mode, OCounters *counters) {
     uint32_t W = ctx->window[0], H = ctx->window[1];
     if (y1 > H) y1 = H;
+    if (x1 > W) x1 = W;
     OCounters total;
     memset(&total, 0, sizeof total);
 #pragma omp parallel
@@ -518,7 +526,7 @@ void oracle_render_rows(const OScene *sc, const OUniform *ctx, float *accum, uin
         memset(&cnt, 0, sizeof cnt);
 #pragma omp for schedule(dynamic, 1) nowait
         for (uint32_t y = y0; y < y1; y++) {
-            for (uint32_t x = 0; x < W; x++) {
+            for (uint32_t x = x0; x < x1; x++) {
                 uint32_t pixel_idx = y * W + x;
                 float uvx = (float)x / (float)W, uvy = (float)y / (float)H;
                 float px = uvx - 0.5f, py = (1.0f - uvy) - 0.5f;

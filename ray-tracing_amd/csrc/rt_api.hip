@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <cstring>
 #include <limits>
@@ -27,12 +28,12 @@
 #include "rt_pack.h"
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
-int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, bool q8);
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, int fmt);
 hipError_t rt_launch_capture(const float *accum, uint8_t *rgb, size_t n_pixels, hipStream_t stream);
 hipError_t rt_launch_deinterleave(const float *gathered, float *image, const RtGatherLayout &L, hipStream_t stream);
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
-                           RtRefitBox *root_out, bool q8, hipStream_t stream);
+                           RtRefitBox *root_out, bool q8, float prim_pad, hipStream_t stream);
 
 namespace {
 
@@ -142,6 +143,9 @@ struct rt_context {
     int opt_node_stride = 0;
     int opt_node_format = 0;         // RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte nodes, 2 32-byte q8 nodes
     bool node_q8 = false;            // format of the nodes on the device
+    bool node_wide = false;          // 80-byte 8-ary nodes (RT_OPT_NODE_FORMAT 3)
+    // the 8-ary format is traversed by every kernel variant
+    bool opt_kernel_wide_ok() const { return true; }
     int opt_kernel = 2;
     int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE, workgroups per CU (0 = all that fit), FETCH weight, -, builder max_leaf, bins
     float4 *d_stage = nullptr;       // per-frame sample sums of a multi-frame launch (lazy, grows)
@@ -179,6 +183,9 @@ struct Repacked {
     std::vector<DevNode> nodes;      // node i; uploaded at 16-byte chunk i * node_stride
     uint32_t node_stride = RT_NODE_CHUNKS;
     bool q8 = false;                 // 32-byte records (rt_pack.h), node_stride 2
+    bool wide = false;               // 80-byte 8-ary nodes (DevNode8) in `nodes8`, node_stride 5
+    std::vector<DevNode8> nodes8;
+    std::vector<uint32_t> order8;    // wide: slot -> primitive id (a node's leaf children are consecutive slots)
     std::vector<int32_t> parent;     // node -> parent * 2 + child slot (device refit)
     bool refit_sources_agree = true; // shading-record corners == BLAS corners (see repack)
     std::vector<DevTri> tris;
@@ -203,9 +210,149 @@ void set_children(DevNode &n, const rt_host::Aabb &box0, int32_t ref0, const rt_
     n.pad = 0;
 }
 
+// The 8-ary tree of RT_OPT_NODE_FORMAT = 3 (DevNode8, rt_device.h), collapsed from the SAH BVH2: a node adopts its
+// grandchildren while it has room (largest surface area first), primitives of BVH2 leaves become one-primitive children.
+// Children get their slots by position (octant order), inner children consecutive node indices, leaf children
+// consecutive primitive slots; big trees are collapsed on several threads (ranges handed out by atomic cursors).
+void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repacked &out) {
+    const uint64_t n_prims = bvh.order.size();
+    out.order8.assign(n_prims, 0u);
+    uint64_t n_inner2 = 0;
+    for (const auto &n : bvh.nodes) if (n.count == 0) n_inner2++;
+    out.nodes8.assign(n_inner2 + 1, DevNode8());
+    memset(out.nodes8.data(), 0, out.nodes8.size() * sizeof(DevNode8));
+    std::atomic<uint64_t> next_node{1}, next_slot{0};
+    std::atomic<uint32_t> max_depth{0};
+    struct Item { uint32_t src, dst, depth; };
+
+    auto half_area = [](const rt_host::Aabb &b) {
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return (dx >= 0.0f && dy >= 0.0f && dz >= 0.0f) ? dx * dy + dy * dz + dz * dx : 0.0f;
+    };
+    // one node: fills out.nodes8[it.dst], appends its inner children to `todo`
+    auto process = [&](const Item &it, std::vector<Item> &todo) {
+        uint32_t open[8];
+        int n_open = 0, total = 0;
+        auto size_of = [&](uint32_t i) { return bvh.nodes[i].count ? (int)bvh.nodes[i].count : 1; };
+        const rt_host::Bvh2Node &src = bvh.nodes[it.src];
+        if (src.count || bvh.nodes.size() == 1) { open[n_open++] = it.src; total = (int)src.count; }      // the whole scene is one leaf (or empty)
+        else { open[0] = src.left; open[1] = src.left + 1; n_open = 2; total = size_of(open[0]) + size_of(open[1]); }
+        for (;;) {
+            int pick = -1;
+            float best = -1.0f;
+            for (int i = 0; i < n_open; i++) {
+                const rt_host::Bvh2Node &c = bvh.nodes[open[i]];
+                if (c.count) continue;
+                if (total - 1 + size_of(c.left) + size_of(c.left + 1) > 8) continue;
+                const float a = half_area(c.box);
+                if (a > best) { best = a; pick = i; }
+            }
+            if (pick < 0) break;
+            const uint32_t l = bvh.nodes[open[pick]].left;
+            total += size_of(l) + size_of(l + 1) - 1;
+            open[pick] = l;
+            open[n_open++] = l + 1;
+        }
+        // children: inner subtrees and single primitives
+        struct Child { bool inner; uint32_t ref; rt_host::Aabb box; };
+        Child ch[8];
+        int n_ch = 0;
+        for (int i = 0; i < n_open; i++) {
+            const rt_host::Bvh2Node &c = bvh.nodes[open[i]];
+            if (!c.count && !(bvh.nodes.size() == 1)) { ch[n_ch++] = {true, open[i], c.box}; continue; }
+            for (uint32_t k = 0; k < c.count && n_ch < 8; k++) {
+                const uint32_t prim = bvh.order[c.left + k];
+                ch[n_ch++] = {false, prim, prim_boxes[prim]};
+            }
+        }
+        // octant slots: greedily give each child the free slot whose direction (+-1, +-1, +-1) its offset from the node's centre favours most
+        float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+        for (int i = 0; i < n_ch; i++)
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], ch[i].box.lo[k]); hi[k] = fmaxf(hi[k], ch[i].box.hi[k]); }
+        float cost[8][8];
+        for (int i = 0; i < n_ch; i++)
+            for (int s8 = 0; s8 < 8; s8++) {
+                float c = 0.0f;
+                for (int k = 0; k < 3; k++) {
+                    const float off = (0.5f * ch[i].box.lo[k] + 0.5f * ch[i].box.hi[k]) - (0.5f * lo[k] + 0.5f * hi[k]);
+                    c += ((s8 >> k) & 1) ? off : -off;
+                }
+                cost[i][s8] = c == c ? c : 0.0f;
+            }
+        int slot_of[8], child_at[8];
+        for (int i = 0; i < 8; i++) { slot_of[i] = -1; child_at[i] = -1; }
+        for (int round = 0; round < n_ch; round++) {
+            int bi = -1, bs = -1;
+            float bc = -3.4e38f;
+            for (int i = 0; i < n_ch; i++) {
+                if (slot_of[i] >= 0) continue;
+                for (int s8 = 0; s8 < 8; s8++)
+                    if (child_at[s8] < 0 && (bi < 0 || cost[i][s8] > bc)) { bc = cost[i][s8]; bi = i; bs = s8; }
+            }
+            slot_of[bi] = bs;
+            child_at[bs] = bi;
+        }
+        uint32_t imask = 0, lmask = 0, n_inner = 0, n_leaf = 0;
+        float blo[8][3], bhi[8][3];
+        for (int s8 = 0; s8 < 8; s8++) {
+            const int i = child_at[s8];
+            if (i < 0) continue;
+            if (ch[i].inner) { imask |= 1u << s8; n_inner++; } else { lmask |= 1u << s8; n_leaf++; }
+            memcpy(blo[s8], ch[i].box.lo, 12);
+            memcpy(bhi[s8], ch[i].box.hi, 12);
+        }
+        const uint64_t base = n_inner ? next_node.fetch_add(n_inner, std::memory_order_relaxed) : 0;
+        const uint64_t slot0 = n_leaf ? next_slot.fetch_add(n_leaf, std::memory_order_relaxed) : 0;
+        DevNode8 &d = out.nodes8[it.dst];
+        d.exps_imask = imask << 24;
+        d.lmask = lmask;
+        d.child_base = (uint32_t)(base * out.node_stride);
+        d.tri_base = (uint32_t)slot0;
+        rt_pack_node8(d, blo, bhi, imask | lmask);
+        uint32_t ki = 0, kl = 0;
+        for (int s8 = 0; s8 < 8; s8++) {
+            const int i = child_at[s8];
+            if (i < 0) continue;
+            if (ch[i].inner) todo.push_back({ch[i].ref, (uint32_t)(base + ki++), it.depth + 1});
+            else out.order8[slot0 + kl++] = ch[i].ref;
+        }
+        uint32_t cur = max_depth.load(std::memory_order_relaxed);
+        while (it.depth > cur && !max_depth.compare_exchange_weak(cur, it.depth, std::memory_order_relaxed)) {}
+    };
+
+    // breadth-first until there is enough independent work, then depth-first per thread
+    std::vector<Item> frontier{{0u, 0u, 0u}};
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const unsigned want = n_prims >= (1u << 18) ? hw * 16u : 0u;
+    size_t head = 0;
+    while (head < frontier.size() && frontier.size() - head < want) { const Item it = frontier[head++]; process(it, frontier); }
+    if (want == 0) { while (head < frontier.size()) { const Item it = frontier[head++]; process(it, frontier); } }
+    if (head < frontier.size()) {
+        std::atomic<size_t> cursor{head};
+        auto worker = [&]() {
+            std::vector<Item> stack;
+            for (;;) {
+                const size_t i = cursor.fetch_add(1, std::memory_order_relaxed);
+                if (i >= frontier.size()) break;
+                stack.push_back(frontier[i]);
+                while (!stack.empty()) { const Item it = stack.back(); stack.pop_back(); process(it, stack); }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < hw; k++) th.emplace_back(worker);
+        worker();
+        for (auto &t : th) t.join();
+    }
+    out.nodes8.resize(next_node.load());
+    // a path pushes at most one two-word group per level below the root (+1 spare)
+    out.stack_entries = 2u * (max_depth.load() + 2u);
+}
+
 void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const std::vector<uint32_t> &ids,
-            const rt_context &ctx, Repacked &out) {
+            const rt_context &ctx, Repacked &out, const rt_host::Aabb *prim_boxes) {
     const uint64_t n_prims = bvh.order.size();     // triangles, then spheres
+    if (out.wide) collapse8(bvh, prim_boxes, out);
+    const std::vector<uint32_t> &order = out.wide ? out.order8 : bvh.order;
     const uint64_t n_real_tris = ids.size() / 2;
     const uint64_t n_tris = n_prims;
     out.tris.resize(n_tris ? n_tris : 1);
@@ -218,7 +365,7 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
     std::atomic<bool> sources_agree{true};
     auto fill = [&](uint64_t slot_lo, uint64_t slot_hi) {
     for (uint64_t slot = slot_lo; slot < slot_hi; slot++) {
-        const uint32_t gid = bvh.order[slot];
+        const uint32_t gid = order[slot];
         DevTri &t = out.tris[slot];
         if (gid >= n_real_tris) {
             const uint32_t si = (uint32_t)(gid - n_real_tris);
@@ -276,6 +423,7 @@ void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const s
         const float m = fmaxf(fabsf(pad_lo(root.box.lo[k])), fabsf(pad_hi(root.box.hi[k])));
         out.scene_abs[k] = m <= 3.0e38f ? m : 3.0e38f;   // non-finite coordinates: every box test passes, still correct
     }
+    if (out.wide) return;            // nodes8 / stack_entries are collapse8's
     if (root.count > 0 || bvh.nodes.size() == 1) {
         // the whole scene is one leaf (or empty): a root whose second child is empty
         out.nodes.resize(1);
@@ -390,14 +538,49 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
         const float r = sp.radius * 1.0001f + 1e-6f;   // the quadratic's roots are not exact
         for (int k = 0; k < 3; k++) { boxes[n_tris + i].lo[k] = sp.center[k] - r; boxes[n_tris + i].hi[k] = sp.center[k] + r; }
     }
+    // Node format (RT_OPT_NODE_FORMAT).  The compact formats (8-bit plane offsets) need the scene's extent to fit their scale range.
+    rt_host::Aabb scene_box;
+    for (int k = 0; k < 3; k++) { scene_box.lo[k] = 3.4e38f; scene_box.hi[k] = -3.4e38f; }
+    bool scene_finite = n_prims > 0;
+    for (uint64_t i = 0; i < n_prims; i++)
+        for (int k = 0; k < 3; k++) {
+            if (!(boxes[i].lo[k] >= -3.0e38f && boxes[i].hi[k] <= 3.0e38f)) scene_finite = false;
+            scene_box.lo[k] = fminf(scene_box.lo[k], boxes[i].lo[k]);
+            scene_box.hi[k] = fmaxf(scene_box.hi[k], boxes[i].hi[k]);
+        }
+    // Every primitive's box is widened by 2^-17 of the scene's largest |coordinate| (rt_pack.h rt_prim_pad): the triangle test's
+    // own rounding grows with the distance between ray origin and triangle and with 1 / |cos| of the incidence, so a ray that
+    // grazes a triangle within rounding of its edge can be ACCEPTED by the test while passing beside the triangle's exact box.
+    // Found by tools/format_diff.py (one pixel-frame of config C4 at 1080p: the binary formats missed a hit that brute force,
+    // the oracle's BVH and the 8-ary format find).  No finite pad is a proof (1 / |cos| is unbounded); this one makes the
+    // case rarer by orders of magnitude for a fraction of a percent of extra box hits.
+    {
+        float scene_r = 0.0f;
+        for (int k = 0; k < 3 && scene_finite; k++) scene_r = fmaxf(scene_r, fmaxf(fabsf(scene_box.lo[k]), fabsf(scene_box.hi[k])));
+        const float pad = rt_prim_pad(scene_r);
+        for (uint64_t i = 0; i < n_prims && scene_finite; i++)
+            for (int k = 0; k < 3; k++) { boxes[i].lo[k] -= pad; boxes[i].hi[k] += pad; }
+        for (int k = 0; k < 3 && scene_finite; k++) { scene_box.lo[k] -= pad; scene_box.hi[k] += pad; }
+    }
+    const bool fits = scene_finite && rt_q8_fits(scene_box.lo, scene_box.hi);
+    // Format by size (RT_OPT_NODE_FORMAT = 0): scenes whose nodes stay in the caches keep 48-byte binary nodes (fewest VALU
+    // instructions per box; C3: 16.0 vs 18.0 ms per step); past ~16 MB of nodes the fetches miss and the 8-ary nodes win
+    // (five fetches for eight boxes, 30 visits per ray instead of 67 on C4: 100.6 vs 110.2 ms per step with 32-byte binary nodes).
+    // A BVH2 over n primitives with leaves of ~2 has ~n inner nodes of 48 bytes.
+    const bool big = n_prims * sizeof(DevNode) / 2 >= (16ull << 20);
+    const bool wide = fits && ctx->opt_kernel_wide_ok() && (ctx->opt_node_format == 3 || (ctx->opt_node_format == 0 && big));
     rt_host::Bvh2 &bvh = ctx->hs->bvh;
-    if (allow_refit && ctx->opt_refit != 0 && ctx->hs->bvh_prims == n_prims && n_prims > 0) {
+    // (a tree built with leaves of more than 4 primitives cannot be collapsed into 8-ary nodes: rebuild)
+    if (allow_refit && ctx->opt_refit != 0 && ctx->hs->bvh_prims == n_prims && n_prims > 0 && !(wide && bvh.max_leaf > 4)) {
         // ≙ acceleration_structure.update(), src/app.rs:61: same primitives, moved
         rt_host::refit_bvh2(boxes.data(), bvh);
         ctx->refits++;
     } else {
         rt_host::BvhBuildOptions opt;
         if (ctx->tune[6] > 0) opt.max_leaf = (uint32_t)ctx->tune[6];
+        // 8-ary nodes hold one primitive per leaf child: every primitive's own box is tested before the primitive is fetched,
+        // so small BVH2 leaves cost nothing extra and two of them must fit one node
+        if (wide) opt.max_leaf = ctx->tune[6] > 0 ? std::min<uint32_t>(opt.max_leaf, 4u) : 2u;
         if (ctx->tune[7] > 0) opt.bins = (uint32_t)ctx->tune[7];
         opt.traversal_cost = ctx->sah_traversal_cost;
         if (ctx->bvh_max_depth > 0) opt.max_depth = ctx->bvh_max_depth;
@@ -409,19 +592,23 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     Repacked &rp = out.rp;
     // Node stride: 48 B (default) packs the tree tightest; 64 B keeps every node inside one 64-B memory sector.
     // Measured: 48 B is 1.5 % faster on C3 (cache-resident), no difference on C4 (2 GB of records).
-    rp.node_stride = ctx->opt_node_stride ? (uint32_t)ctx->opt_node_stride : (uint32_t)RT_NODE_CHUNKS;
-    {
-        // Node format (rt_pack.h): 32-byte q8 records when the scene's extent fits AND the nodes are too
-        // many to stay in the caches (measured: C4, 244 MB of 48-byte nodes, 8 % faster; C3, 0.26 MB, 2 % slower)
-        const bool fits = n_prims > 0 && rt_q8_fits(bvh.nodes[0].box.lo, bvh.nodes[0].box.hi);
-        rp.q8 = fits && (ctx->opt_node_format == 2 || (ctx->opt_node_format == 0 && bvh.nodes.size() * sizeof(DevNode) / 2 >= (16ull << 20)));
-        if (rp.q8) rp.node_stride = 2;
-    }
-    repack(bvh, corners, ids, *ctx, rp);
+    rp.node_stride = (ctx->opt_node_stride == 3 || ctx->opt_node_stride == 4) ? (uint32_t)ctx->opt_node_stride : (uint32_t)RT_NODE_CHUNKS;
+    // 8-ary nodes (format 3) wherever they fit; else binary nodes: 32-byte q8 records when the scene's extent fits AND the
+    // nodes are too many to stay in the caches (measured: C4, 244 MB of 48-byte nodes, 8 % faster; C3, 0.26 MB, 2 % slower)
+    rp.wide = wide;
+    rp.q8 = !wide && fits && ctx->opt_node_format == 2;
+    if (rp.q8) rp.node_stride = 2;
+    if (rp.wide) rp.node_stride = ctx->opt_node_stride == 8 ? 8u : (uint32_t)RT_NODE8_CHUNKS;
+    repack(bvh, corners, ids, *ctx, rp, boxes.data());
     out.build_seconds = bvh.build_seconds;
     out.n_prims = n_prims;
     convert_materials(*ctx, out.mats);
-    if (rp.node_stride != RT_NODE_CHUNKS) {
+    if (rp.wide && rp.node_stride != RT_NODE8_CHUNKS) {
+        const size_t pitch = (size_t)rp.node_stride * 16u;
+        out.packed_nodes.assign(rp.nodes8.size() * pitch, 0);
+        for (size_t i = 0; i < rp.nodes8.size(); i++) memcpy(out.packed_nodes.data() + i * pitch, &rp.nodes8[i], sizeof(DevNode8));
+    }
+    if (!rp.wide && rp.node_stride != RT_NODE_CHUNKS) {
         // other strides (64-byte slots, 32-byte q8 records = the first 32 bytes of a DevNode): restride on the host and
         // upload in one piece (a pitched copy of 10^8 32-byte rows takes minutes)
         const size_t pitch = (size_t)rp.node_stride * 16u, row = pitch < sizeof(DevNode) ? pitch : sizeof(DevNode);
@@ -442,19 +629,22 @@ int device_upload(rt_context *ctx, const Built &b) {
     ctx->models_committed = true;    // from here on the device scene is being replaced
     ctx->have_scene = false;
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
-    const size_t node_bytes = rp.nodes.size() * (size_t)rp.node_stride * 16u;
+    const size_t n_nodes = rp.wide ? rp.nodes8.size() : rp.nodes.size();
+    const size_t node_bytes = n_nodes * (size_t)rp.node_stride * 16u;
     RT_HIP(hipMalloc((void **)&ctx->d_nodes, node_bytes));
     RT_HIP(hipMalloc((void **)&ctx->d_tris, rp.tris.size() * sizeof(DevTri)));
     RT_HIP(hipMalloc((void **)&ctx->d_shade, rp.shade.size() * sizeof(DevShade)));
     RT_HIP(hipMalloc((void **)&ctx->d_materials, mats.size() * sizeof(DevMaterial)));
     ctx->materials_capacity = mats.size();
-    RT_HIP(hipMemcpy(ctx->d_nodes, rp.node_stride == RT_NODE_CHUNKS ? (const void *)rp.nodes.data() : (const void *)b.packed_nodes.data(),
-                     node_bytes, hipMemcpyHostToDevice));
+    const void *node_src = rp.wide ? (rp.node_stride == RT_NODE8_CHUNKS ? (const void *)rp.nodes8.data() : (const void *)b.packed_nodes.data())
+                                   : (rp.node_stride == RT_NODE_CHUNKS ? (const void *)rp.nodes.data() : (const void *)b.packed_nodes.data());
+    RT_HIP(hipMemcpy(ctx->d_nodes, node_src, node_bytes, hipMemcpyHostToDevice));
+    ctx->node_wide = rp.wide;
     ctx->node_bytes = node_bytes;
     ctx->node_stride = rp.node_stride;
     ctx->node_q8 = rp.q8;
     dev_free(ctx->d_parent); dev_free(ctx->d_arrived); dev_free(ctx->d_cbox); dev_free(ctx->d_tribox); dev_free(ctx->d_root); dev_free(ctx->d_xform);
-    if (ctx->opt_refit == 2 && rp.refit_sources_agree && rp.parent.size() == rp.nodes.size() && rp.nodes.size() > 1) {
+    if (ctx->opt_refit == 2 && !rp.wide && rp.refit_sources_agree && rp.parent.size() == rp.nodes.size() && rp.nodes.size() > 1) {
         const size_t nn = rp.nodes.size();
         RT_HIP(hipMalloc((void **)&ctx->d_parent, nn * sizeof(int32_t)));
         RT_HIP(hipMalloc((void **)&ctx->d_arrived, nn * sizeof(unsigned int)));
@@ -467,7 +657,7 @@ int device_upload(rt_context *ctx, const Built &b) {
     RT_HIP(hipMemcpy(ctx->d_tris, rp.tris.data(), rp.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_shade, rp.shade.data(), rp.shade.size() * sizeof(DevShade), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(DevMaterial), hipMemcpyHostToDevice));
-    ctx->n_nodes = rp.nodes.size();
+    ctx->n_nodes = n_nodes;
     ctx->n_tris = n_prims;
     ctx->stack_entries = rp.stack_entries;
     memcpy(ctx->scene_abs, rp.scene_abs, sizeof(ctx->scene_abs));
@@ -543,6 +733,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
         P.stage_stride = (uint64_t)P.local_rows * ctx->width;
     }
     P.node_q8 = ctx->node_q8 ? 1u : 0u;
+    P.node_wide = ctx->node_wide ? 1u : 0u;
     P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
     P.textures = ctx->d_textures; P.texels = ctx->d_texels; P.n_textures = ctx->n_textures;
     P.n_materials = (uint32_t)ctx->materials_capacity;      // records actually uploaded (the LDS preload copies that many)
@@ -577,6 +768,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
     P.right[0] = right.x; P.right[1] = right.y; P.right[2] = right.z;
     P.up[0] = up.x; P.up[1] = up.y; P.up[2] = up.z;
     P.n_node_chunks = (uint32_t)(ctx->node_bytes / 16u);
+    P.wide_stride = ctx->node_stride;
     P.n_slots = ctx->n_tris;
     P.queue = static_scratch ? reinterpret_cast<DevQueue *>(static_scratch) : ctx->d_queue;
     memcpy(P.tune, ctx->tune, sizeof P.tune);
@@ -588,9 +780,9 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
         RT_HIP(hipMemsetAsync(P.queue, 0, sizeof(DevQueue), ctx->stream));     // the head must start at zero, whatever the last call left
         const bool ext = !ctx->hs->spheres.empty() || ctx->n_textures > 0;
         const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
-        const int sel = (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
+        const int sel = (ctx->node_wide ? 32 : 0) | (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
         if (ctx->persistent_blocks == 0 || ctx->persistent_sel != sel) {
-            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm, ctx->node_q8);
+            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm, ctx->node_wide ? 2 : (ctx->node_q8 ? 1 : 0));
             ctx->persistent_sel = sel;
             if (ctx->tune[3] > 0 && ctx->cu_count > 0 && ctx->persistent_blocks > ctx->tune[3] * ctx->cu_count)
                 ctx->persistent_blocks = ctx->tune[3] * ctx->cu_count;       // developer knob 103: workgroups per CU
@@ -640,7 +832,7 @@ int check_dispatch(rt_context *ctx, const RtUniform *u) {
                     u->window[0], u->window[1], ctx->width, ctx->height);
     if ((uint64_t)u->window[0] * u->window[1] > 0xFFFFFFFFull)
         return fail(RT_ERR_INVALID_ARGUMENT, "window has more than 2^32 pixels");
-    if ((uint64_t)ctx->stack_entries * 256u * 4u + RT_LDS_MATERIALS * 64u > 160u * 1024u)      // traversal stacks + the material copy
+    if ((uint64_t)ctx->stack_entries * 256u * 4u + RT_LDS_MATERIALS * 64u + 2048u > 160u * 1024u)      // traversal stacks + the material copy + the 8-ary nodes' child-order table
         return fail(RT_ERR_INVALID_ARGUMENT, "BVH depth %u needs more LDS than a CU has", ctx->stack_entries);
     RT_HIP(hipSetDevice(ctx->device));
     if (ctx->opt_aov) { int r = ensure_aov(ctx); if (r) return r; }
@@ -665,7 +857,8 @@ int device_refit(rt_context *ctx) {
         xform = ctx->d_xform;
     }
     RT_HIP(rt_launch_refit(ctx->d_tris, ctx->d_shade, xform, ctx->d_tribox, ctx->n_tris, reinterpret_cast<float4 *>(ctx->d_nodes), ctx->node_stride,
-                           ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, ctx->node_q8, ctx->stream));
+                           ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, ctx->node_q8,
+                           rt_prim_pad(fmaxf(ctx->scene_abs[0], fmaxf(ctx->scene_abs[1], ctx->scene_abs[2]))), ctx->stream));
     RtRefitBox root;
     RT_HIP(hipMemcpyAsync(&root, ctx->d_root, sizeof root, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));                   // also keeps `mats` / `resolved` alive long enough
@@ -705,6 +898,11 @@ int rt_create(int device_id, rt_context **out) {
     }
     rt_context *ctx = new rt_context();
     ctx->device = device_id;
+    // developer default for RT_OPT_NODE_FORMAT (tests/test_gpu_wide_nodes.py runs the whole parity suite on the 8-ary format this way)
+    if (const char *e = getenv("RT_AMD_NODE_FORMAT")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 3) ctx->opt_node_format = v;
+    }
     (void)hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device_id);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
@@ -760,11 +958,11 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             return RT_OK;
         case RT_OPT_FRAME_PIPELINE: ctx->opt_pipeline = value != 0; return RT_OK;
         case RT_OPT_NODE_FORMAT:
-            if (value < 0 || value > 2) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_FORMAT: 0 (by size), 1 (48-byte) or 2 (32-byte)");
+            if (value < 0 || value > 3) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_FORMAT: 0 (automatic), 1 (48-byte binary), 2 (32-byte binary) or 3 (80-byte 8-ary)");
             ctx->opt_node_format = (int)value;
             return RT_OK;
         case RT_OPT_NODE_STRIDE:
-            if (value != 0 && value != 3 && value != 4) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_STRIDE: 0 (auto), 3 or 4");
+            if (value != 0 && value != 3 && value != 4 && value != 8) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_STRIDE: 0 (auto), 3 or 4 (binary nodes), 8 (8-ary nodes)");
             ctx->opt_node_stride = value;
             return RT_OK;
         default:

@@ -31,6 +31,27 @@ struct alignas(16) DevNode {
 static_assert(sizeof(DevNode) == 48, "DevNode");
 #define RT_NODE_CHUNKS 3                        // 16-byte chunks per node
 
+// The wide node (RT_OPT_NODE_FORMAT = 3): an 8-ary BVH node of 80 bytes = five 16-byte fetches for EIGHT child boxes
+// (the 48-byte binary node: three fetches for two).  The L1 path's cost is per lane-load instruction, so
+// fetches per ray are what this record minimises: ~4 visits x 5 fetches instead of ~12 x 3.
+//   - child boxes: 8-bit plane offsets from the node's f32 lower corner in units of a per-axis power of two
+//     (scale_k = 2^(exp_k - 127)), rounded outward; per axis and child PAIR p one dword [c(2p).lo, c(2p+1).lo, c(2p).hi,
+//     c(2p+1).hi], so rotating it by 16 bits swaps the planes a ray enters and leaves through (as in the q8 binary node);
+//   - children are either inner nodes (bit in imask) or ONE primitive each (bit in lmask), or absent;
+//   - a node's inner children are consecutive nodes starting at child_base, its leaf children's primitives consecutive
+//     slots starting at tri_base, both in child-slot order: child i is node child_base + 5 * popcount(imask & below(i))
+//     (child_base is a 16-byte chunk index) or slot tri_base + popcount(lmask & below(i)) — no per-child references;
+//   - child slots are assigned at build time by position: slot bit k set = the child lies towards +axis k from the
+//     node's centre, so that slot XOR (ray direction signs) orders children near to far without sorting (the octant
+//     order of Ylitie, Karras & Laine, "Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs", 2017).
+struct alignas(16) DevNode8 {
+    float lox, loy, loz; uint32_t exps_imask;   // bytes 0..2: biased exponents of the x, y, z scales; byte 3: imask
+    uint32_t child_base, tri_base, lmask, pad;
+    uint32_t qx[4], qy[4], qz[4];
+};
+static_assert(sizeof(DevNode8) == 80, "DevNode8");
+#define RT_NODE8_CHUNKS 5
+
 // Child reference: >= 0 → inner DevNode, as its index * RT_NODE_CHUNKS (a
 // float4 index: the address needs a shift only); < 0 → leaf, with
 // ~ref = (first_slot << 3) | count, count in 0..7 (0 = empty child).
@@ -113,7 +134,8 @@ struct RenderParams {
     const DevMaterial *materials;
     const DevTexture *textures;   // EXT builds only
     const uint32_t *texels;
-    uint32_t node_q8, pad_q8;            // 1: nodes are 32-byte records with 8-bit plane offsets (rt_pack.h), stride 2 chunks
+    uint32_t node_q8, node_wide;         // node_q8 = 1: 32-byte binary nodes with 8-bit plane offsets (rt_pack.h), stride 2 chunks;
+                                         // node_wide = 1: 80-byte 8-ary nodes (DevNode8), `nodes` points at them
     uint32_t n_textures, n_materials;   // n_materials: records behind `materials`
     float *accum;            // local rows x W x 4 f32
     uint32_t *aov;           // local rows x W x 2 u32, or null
@@ -144,7 +166,7 @@ struct RenderParams {
     float scene_abs[3];                  // max |coordinate| of the BVH root box per axis (slab-test error bound)
     // RT_GUARD builds (make guard): what traversal references are checked against before they are used
     uint32_t n_node_chunks;              // 16-byte chunks in the node array
-    uint32_t guard_pad;
+    uint32_t wide_stride;                // 8-ary nodes: 16-byte chunks from one node to the next (5 = packed, 8 = one node per 128-byte line)
     uint64_t n_slots;                    // triangle / sphere records
     int32_t tune[8];                     // scheduler weights: [0] NODE, [1] LEAF, [2] SHADE, [4] FETCH (others unused by the kernel)
 #ifdef RT_TAIL_PROBE

@@ -53,6 +53,9 @@ __shared__ float4 g_lds_materials[RT_LDS_MATERIALS * 4u];   // LDSM instances of
 #ifndef RT_PHASED_WAVES
 #define RT_PHASED_WAVES 5                    // waves per SIMD the phased kernel must fit (96 VGPRs); it fits 6 (80) as built, see Makefile
 #endif
+#ifndef RT_PHASED_WAVES_WIDE
+#define RT_PHASED_WAVES_WIDE 6               // the 8-ary instance is held to 80 VGPRs (12 bytes of scratch): 6 waves per SIMD instead of 5
+#endif
 constexpr float kTMin = 0.001f;              // main.wgsl:77
 constexpr float kTMax = 3.40282347e+38f;     // main.wgsl:77
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
@@ -245,6 +248,123 @@ __device__ __forceinline__ Hit trace(const RenderParams &P, uint32_t *__restrict
         if (sp == 0) return best;
         sp--;
         cur = (int32_t)stack[sp * kBlock];
+    }
+}
+
+
+// ---- 8-ary nodes (DevNode8, rt_device.h; RT_OPT_NODE_FORMAT 3) ----
+// Traversal state of a ray is two GROUPS instead of one reference: the hit inner children of the last node visited
+// (ng_base = chunk index of the node's first inner child, ng_mask = hit bits | imask << 8) and its hit one-primitive
+// children (tg_base = first primitive slot, tg_mask = hit bits | lmask << 8).  A child's record is found by counting the
+// imask / lmask bits below its slot.  Among the hit children of a group the next one taken is the one with the smallest
+// (slot XOR direction signs): child slots are assigned by octant at build time, so that is near-to-far order without
+// sorting — looked up in a 2 KiB table in LDS (g_lds_next_slot[signs << 8 | hits]).  The stack holds groups (two words
+// per entry); a visit pushes at most one, so it is as deep as the TREE (7 levels for 11k triangles, ~13 for 200 M).
+__shared__ unsigned char g_lds_next_slot[8 * 256];
+
+__device__ __forceinline__ void fill_next_slot_table() {
+    for (uint32_t i = threadIdx.x; i < 8u * 256u; i += kBlock) {
+        const uint32_t flip = i >> 8, hits = i & 255u;
+        uint32_t best_slot = 0, best_key = 8;
+        for (uint32_t sl = 0; sl < 8; sl++)
+            if (((hits >> sl) & 1u) && (sl ^ flip) < best_key) { best_key = sl ^ flip; best_slot = sl; }
+        g_lds_next_slot[i] = (unsigned char)best_slot;
+    }
+    __syncthreads();
+}
+
+// inverse direction with the node step's rotate amount (16 for a negative component, else 0) in mantissa bits 4:0
+__device__ __forceinline__ float stuffed_inverse(float dcomp) {
+    const float nz = fabsf(dcomp) < 1e-30f ? copysignf(1e-30f, dcomp) : dcomp;
+    const uint32_t u = __float_as_uint(__builtin_amdgcn_rcpf(nz));
+    return __uint_as_float((u & 0xFFFFFFE0u) | ((u >> 27) & 16u));
+}
+
+__device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 255u); }
+
+// One visit: all eight child boxes of the node at 16-byte chunk `chunk` against the ray (ix.. = stuffed inverses, ox.. =
+// -o * inv, eps: see make_slab).  Returns the hit mask over the node's present children.  Conservative like the binary
+// nodes' test: planes are rounded outward at build time, the far bound is widened by kFarSlack and eps.
+__device__ __forceinline__ uint32_t test_node8(const float4 *__restrict__ n, float ix, float iy, float iz, float ox, float oy, float oz,
+                                               float eps, float tbest, uint32_t &child_base, uint32_t &tri_base, uint32_t &imask, uint32_t &lmask) {
+    const float4 a = ld4(n);
+    const uint4 b = ld4u(n + 1), qx = ld4u(n + 2), qy = ld4u(n + 3), qz = ld4u(n + 4);
+    const uint32_t w = __float_as_uint(a.w);
+    // per-axis scale 2^(byte - 127) times the inverse direction
+    const float sx = __uint_as_float((w & 0xffu) << 23) * ix, sy = __uint_as_float(((w >> 8) & 0xffu) << 23) * iy,
+                sz = __uint_as_float(((w >> 16) & 0xffu) << 23) * iz;
+    const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
+    const uint32_t rx = __float_as_uint(ix), ry = __float_as_uint(iy), rz = __float_as_uint(iz);
+    const uint32_t QX[4] = {qx.x, qx.y, qx.z, qx.w}, QY[4] = {qy.x, qy.y, qy.z, qy.w}, QZ[4] = {qz.x, qz.y, qz.z, qz.w};
+    uint32_t h = 0;
+    // children 7 .. 0, so that the mask can be built by shifting each hit in from below: h = 2 h + hit is ONE v_addc
+    // (carry-in = the compare's result) instead of a select and an or
+#pragma unroll
+    for (int p = 3; p >= 0; p--) {
+        // [c(2p).lo, c(2p+1).lo, c(2p).hi, c(2p+1).hi] rotated by 0 or 16 bits: bytes 0, 1 = the planes the ray ENTERS through
+        const uint32_t px = __builtin_amdgcn_alignbit(QX[p], QX[p], rx), py = __builtin_amdgcn_alignbit(QY[p], QY[p], ry),
+                       pz = __builtin_amdgcn_alignbit(QZ[p], QZ[p], rz);
+#pragma unroll
+        for (int j = 1; j >= 0; j--) {
+            const float tn = fmaxf(fmaxf(fmaf(ubyte_f(px, j), sx, bx), fmaf(ubyte_f(py, j), sy, by)), fmaxf(fmaf(ubyte_f(pz, j), sz, bz), kTMin));
+            const float tf = fminf(fminf(fmaf(ubyte_f(px, 2 + j), sx, bx), fmaf(ubyte_f(py, 2 + j), sy, by)), fminf(fmaf(ubyte_f(pz, 2 + j), sz, bz), tbest));
+            const float lim = fmaf(tf, kFarSlack, eps);
+            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(tn), "v"(lim) : "vcc");
+        }
+    }
+    imask = w >> 24;
+    lmask = b.z & 0xffu;
+    child_base = b.x;
+    tri_base = b.y;
+    return h & (imask | lmask);
+}
+
+// nearest committed hit through the 8-ary tree, one whole ray per call (kernel variants 0 and 1)
+template <bool COUNT, bool SPH>
+__device__ __forceinline__ Hit trace8(const RenderParams &P, uint32_t *__restrict__ stack, rt_v3 o, rt_v3 d, Tally &tl) {
+    Hit best;
+    best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
+    const bool cull = (P.flags & 1u) != 0;
+    const bool cw = P.front_face_cw != 0;
+    const float ix = stuffed_inverse(d.x), iy = stuffed_inverse(d.y), iz = stuffed_inverse(d.z);
+    const float ox = -(o.x * ix), oy = -(o.y * iy), oz = -(o.z * iz);
+    const float eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(ox)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(oy))),
+                                             fmaf(P.scene_abs[2], fabsf(iz), fabsf(oz)));
+    const uint32_t flip256 = ((__float_as_uint(ix) >> 31) | ((__float_as_uint(iy) >> 31) << 1) | ((__float_as_uint(iz) >> 31) << 2)) << 8;
+    const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(P.nodes);
+    uint32_t ng_base = 0, ng_mask = 0x0101u, tg_base = 0, tg_mask = 0;   // the root: the only child of a virtual group
+    int sp = 0;
+    unsigned steps = 0;
+    for (;;) {
+        if (kGuard && ++steps > kGuardMaxSteps) { tl.guard++; return best; }
+        if (tg_mask & 0xffu) {
+            const uint32_t slot = g_lds_next_slot[flip256 | (tg_mask & 0xffu)];
+            tg_mask &= ~(1u << slot);
+            const uint32_t tri = tg_base + (uint32_t)__popc((tg_mask >> 8) & ((1u << slot) - 1u));
+            if (kGuard && tri >= P.n_slots) { tl.guard++; return best; }
+            if (COUNT) { tl.tris++; if (first_active_lane()) tl.w_leaf++; }
+            intersect_tri<SPH>(P.tris, tri, o, d, cull, cw, best);
+            continue;
+        }
+        if (!(ng_mask & 0xffu)) {
+            if (sp == 0) return best;
+            sp -= 2;
+            ng_base = stack[sp * kBlock];
+            ng_mask = stack[(sp + 1) * kBlock];
+        }
+        const uint32_t slot = g_lds_next_slot[flip256 | (ng_mask & 0xffu)];
+        ng_mask &= ~(1u << slot);
+        const uint32_t node = ng_base + P.wide_stride * (uint32_t)__popc((ng_mask >> 8) & ((1u << slot) - 1u));
+        if (ng_mask & 0xffu) {
+            if (kGuard && (uint32_t)(sp + 2) > P.stack_entries) { tl.guard++; }
+            else { stack[sp * kBlock] = ng_base; stack[(sp + 1) * kBlock] = ng_mask; sp += 2; }
+        }
+        if (kGuard && node + 5u > P.n_node_chunks) { tl.guard++; return best; }
+        if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
+        uint32_t imask, lmask;
+        const uint32_t h = test_node8(nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
+        ng_mask = (h & imask) | (imask << 8);
+        tg_mask = (h & lmask) | (lmask << 8);
     }
 }
 
@@ -488,7 +608,7 @@ __device__ __forceinline__ bool shade(const RenderParams &P, const Camera &C, Pi
 
 template <bool COUNT, bool AOV, bool SPH>
 __device__ __forceinline__ bool step(const RenderParams &P, const Camera &C, uint32_t *stack, PixelState &S, Tally &tl) {
-    Hit h = trace<COUNT, SPH>(P, stack, S.pos, S.dir, tl);          // main.wgsl:44
+    Hit h = P.node_wide ? trace8<COUNT, SPH>(P, stack, S.pos, S.dir, tl) : trace<COUNT, SPH>(P, stack, S.pos, S.dir, tl);   // main.wgsl:44
     tl.rays++;
     return shade<AOV, SPH>(P, C, S, h);
 }
@@ -545,6 +665,7 @@ template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
+    if (P.node_wide) fill_next_slot_table();
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t total_slots = P.tiles_x * P.local_bands * 64u;
     const Camera C = load_camera(P);
@@ -606,10 +727,13 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_FETCH = 4, PH_DONE = 5 };
 constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel-frame that has not started its first path
 
-template <bool COUNT, bool AOV, bool SPH, bool LDSM, bool Q8>
-__global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
+// FMT: node format — 0 = 48-byte binary nodes, 1 = 32-byte binary nodes (q8), 2 = 80-byte 8-ary nodes (DevNode8)
+template <bool COUNT, bool AOV, bool SPH, bool LDSM, int FMT>
+__global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
+    constexpr bool Q8 = FMT == 1, WIDE = FMT == 2;
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
+    if (WIDE) fill_next_slot_table();
     if (LDSM) {       // the host picks this instance when P.n_materials <= RT_LDS_MATERIALS
         if (threadIdx.x < P.n_materials * 4u) g_lds_materials[threadIdx.x] = reinterpret_cast<const float4 *>(P.materials)[threadIdx.x];
         __syncthreads();
@@ -630,6 +754,8 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
     int phase = PH_FETCH;
     bool have_pixel = false;  // FETCH: a finished pixel-frame waits to be written out
     int32_t cur = 0;          // NODE: inner node reference (float4 index); LEAF: leaf reference (< 0)
+    // 8-ary nodes: the ray's two groups (see test_node8) and the table row of its direction signs
+    uint32_t ng_base = 0, ng_mask = 0, tg_base = 0, tg_mask = 0, flip256 = 0;
     uint32_t *sptr = stack;   // next free entry of the lane's LDS stack (entries are kBlock words apart)
     unsigned guard_steps = 0; // RT_GUARD: traversal steps of the current ray
     uint32_t *const stack_end = stack + (size_t)P.stack_entries * kBlock;
@@ -648,8 +774,20 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                                      fmaf(P.scene_abs[2], fabsf(iz), fabsf(oz)));   // see make_slab
         best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
         cur = 0; sptr = stack;
+        if (WIDE) {
+            ng_base = 0; ng_mask = 0x0101u; tg_mask = 0;      // the root: the only child of a virtual group
+            flip256 = ((__float_as_uint(ix) >> 31) | ((__float_as_uint(iy) >> 31) << 1) | ((__float_as_uint(iz) >> 31) << 2)) << 8;
+        }
         guard_steps = 0;
         phase = PH_NODE;
+    };
+    // 8-ary nodes: what a lane does next once its current step is done — primitives of the node just visited first, then
+    // its inner children, then the youngest group on the stack; nothing left = the trace is finished
+    auto wide_advance = [&]() {
+        if (tg_mask & 0xffu) phase = PH_LEAF;
+        else if (ng_mask & 0xffu) phase = PH_NODE;
+        else if (sptr == stack) phase = PH_SHADE;
+        else { sptr -= 2 * kBlock; ng_base = sptr[0]; ng_mask = sptr[kBlock]; phase = PH_NODE; }
     };
     // wave-uniform choice of the next phase body: the one most lanes wait for,
     // weighted (P.tune) so cheap bodies run at lower occupancy than expensive ones
@@ -679,8 +817,28 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
                 for (int rep = 0; rep < RT_NODE_REPS; rep++) {
                 // back to the scheduler early once fewer than 1/RT_NODE_EARLY_OUT of the lanes that came in are still on nodes
                 if (rep > 0 && __popcll(__ballot(phase == PH_NODE)) * RT_NODE_EARLY_OUT < node_lanes) break;
-                if (kGuard && phase == PH_NODE &&
+                if (kGuard && !WIDE && phase == PH_NODE &&
                     ((uint32_t)cur + (Q8 ? 2u : 3u) > P.n_node_chunks || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
+                if (WIDE) {
+                    if (phase == PH_NODE) {
+                        const uint32_t slot = g_lds_next_slot[flip256 | (ng_mask & 0xffu)];
+                        ng_mask &= ~(1u << slot);
+                        const uint32_t node = ng_base + P.wide_stride * (uint32_t)__popc((ng_mask >> 8) & ((1u << slot) - 1u));
+                        if (kGuard && (node + 5u > P.n_node_chunks || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
+                        else {
+                            if (ng_mask & 0xffu) {               // siblings still to visit: the group goes on the stack
+                                if (kGuard && sptr + kBlock >= stack_end) { tl.guard++; }
+                                else { sptr[0] = ng_base; sptr[kBlock] = ng_mask; sptr += 2 * kBlock; }
+                            }
+                            if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
+                            uint32_t imask, lmask;
+                            const uint32_t h = test_node8(nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
+                            ng_mask = (h & imask) | (imask << 8);
+                            tg_mask = (h & lmask) | (lmask << 8);
+                            wide_advance();
+                        }
+                    }
+                } else
                 if (phase == PH_NODE) {
                     if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
                     const float4 *n = nodes + cur;
@@ -747,9 +905,23 @@ __global__ __launch_bounds__(kBlock, RT_PHASED_WAVES) void rt_render_phased(cons
             do {
 #pragma unroll
                 for (int rep = 0; rep < RT_LEAF_REPS; rep++) {
+                if (WIDE) {
+                    if (phase == PH_LEAF) {
+                        // one hit primitive of the node's leaf children, nearest octant first
+                        const uint32_t slot = g_lds_next_slot[flip256 | (tg_mask & 0xffu)];
+                        tg_mask &= ~(1u << slot);
+                        const uint32_t tri = tg_base + (uint32_t)__popc((tg_mask >> 8) & ((1u << slot) - 1u));
+                        if (kGuard && (tri >= P.n_slots || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
+                        else {
+                            if (COUNT) { tl.tris++; if (first_active_lane()) tl.w_leaf++; }
+                            intersect_tri<SPH>(P.tris, tri, S.pos, S.dir, cull, cw, best);
+                            wide_advance();
+                        }
+                    }
+                } else
                 if (kGuard && phase == PH_LEAF &&
                     ((uint64_t)((uint32_t)~cur >> 3) + ((uint32_t)~cur & 7u) > P.n_slots || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
-                if (phase == PH_LEAF) {
+                if (!WIDE && phase == PH_LEAF) {
                     // ~cur = first_slot << 3 | triangles left: tested last to first, the count runs down in place
                     uint32_t enc = (uint32_t)~cur;
                     if (enc & 7u) {
@@ -874,6 +1046,7 @@ template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock) void rt_render_tiles(const RenderParams P) {
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
+    if (P.node_wide) fill_next_slot_table();
     const uint32_t tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const uint32_t tiles_total = P.tiles_x * P.local_bands;
     const Camera C = load_camera(P);
@@ -908,29 +1081,31 @@ hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const Ren
 // Persistent grid size: the number of 256-thread workgroups of the given kernel
 // instance that are resident at once (register/LDS limited), so every wave
 // lives for the whole launch.
-template <bool LDSM, bool Q8>
+template <bool LDSM, int FMT>
 static const void *phased_instance(int sel) {
     switch (sel) {
-        case 0: return (const void *)rt_render_phased<false, false, false, LDSM, Q8>;
-        case 1: return (const void *)rt_render_phased<false, false, true, LDSM, Q8>;
-        case 2: return (const void *)rt_render_phased<false, true, false, LDSM, Q8>;
-        case 3: return (const void *)rt_render_phased<false, true, true, LDSM, Q8>;
-        case 4: return (const void *)rt_render_phased<true, false, false, LDSM, Q8>;
-        case 5: return (const void *)rt_render_phased<true, false, true, LDSM, Q8>;
-        case 6: return (const void *)rt_render_phased<true, true, false, LDSM, Q8>;
-        default: return (const void *)rt_render_phased<true, true, true, LDSM, Q8>;
+        case 0: return (const void *)rt_render_phased<false, false, false, LDSM, FMT>;
+        case 1: return (const void *)rt_render_phased<false, false, true, LDSM, FMT>;
+        case 2: return (const void *)rt_render_phased<false, true, false, LDSM, FMT>;
+        case 3: return (const void *)rt_render_phased<false, true, true, LDSM, FMT>;
+        case 4: return (const void *)rt_render_phased<true, false, false, LDSM, FMT>;
+        case 5: return (const void *)rt_render_phased<true, false, true, LDSM, FMT>;
+        case 6: return (const void *)rt_render_phased<true, true, false, LDSM, FMT>;
+        default: return (const void *)rt_render_phased<true, true, true, LDSM, FMT>;
     }
 }
 
-int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, bool q8) {
+// fmt: 0 = 48-byte binary nodes, 1 = 32-byte binary nodes, 2 = 8-ary nodes
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, int fmt) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
     const size_t lds = (size_t)stack_entries * kBlock * sizeof(uint32_t);
     // the instances differ in register count (and static LDS), hence in how many workgroups fit
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
-    const void *fn = lds_materials ? (q8 ? phased_instance<true, true>(sel) : phased_instance<true, false>(sel))
-                                   : (q8 ? phased_instance<false, true>(sel) : phased_instance<false, false>(sel));
+    const void *fn;
+    if (lds_materials) fn = fmt == 2 ? phased_instance<true, 2>(sel) : (fmt == 1 ? phased_instance<true, 1>(sel) : phased_instance<true, 0>(sel));
+    else fn = fmt == 2 ? phased_instance<false, 2>(sel) : (fmt == 1 ? phased_instance<false, 1>(sel) : phased_instance<false, 0>(sel));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu * prop.multiProcessorCount;
 }
@@ -941,11 +1116,16 @@ static hipError_t launch_variant(const RenderParams &P, int variant, dim3 tile_g
     if (variant == 1) return launch(rt_render_tiles<COUNT, AOV, SPH>, tile_grid, lds, stream, P);
     if (variant == 0) return launch(rt_render_persistent<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
     // LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS); Q8: 32-byte nodes
-    const bool ldsm = P.n_materials <= RT_LDS_MATERIALS, q8 = P.node_q8 != 0u;
-    if (ldsm && q8) return launch(rt_render_phased<COUNT, AOV, SPH, true, true>, persistent_grid, lds, stream, P);
-    if (ldsm) return launch(rt_render_phased<COUNT, AOV, SPH, true, false>, persistent_grid, lds, stream, P);
-    if (q8) return launch(rt_render_phased<COUNT, AOV, SPH, false, true>, persistent_grid, lds, stream, P);
-    return launch(rt_render_phased<COUNT, AOV, SPH, false, false>, persistent_grid, lds, stream, P);
+    const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
+    const int fmt = P.node_wide ? 2 : (P.node_q8 ? 1 : 0);
+    if (ldsm) {
+        if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, true, 2>, persistent_grid, lds, stream, P);
+        if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, true, 1>, persistent_grid, lds, stream, P);
+        return launch(rt_render_phased<COUNT, AOV, SPH, true, 0>, persistent_grid, lds, stream, P);
+    }
+    if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, false, 2>, persistent_grid, lds, stream, P);
+    if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, false, 1>, persistent_grid, lds, stream, P);
+    return launch(rt_render_phased<COUNT, AOV, SPH, false, 0>, persistent_grid, lds, stream, P);
 }
 
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream) {

@@ -13,6 +13,9 @@
 RT_HD float rt_pad_lo(float v) { return v - (fabsf(v) * 4.76837158e-7f + 1e-30f); }
 RT_HD float rt_pad_hi(float v) { return v + (fabsf(v) * 4.76837158e-7f + 1e-30f); }
 
+// Absolute widening of every PRIMITIVE's box, from the scene's largest |coordinate| (see rt_api.hip host_build)
+RT_HD float rt_prim_pad(float scene_max_abs) { return scene_max_abs <= 3.0e38f ? scene_max_abs * 7.62939453125e-6f : 0.0f; }   // 2^-17
+
 // x >= 0 → the f16 bit pattern nearest to x from below (up = false) or above (up = true).
 // Above saturates to +inf, below to 65504; a non-zero upper bound is never an f16
 // denormal, so a flush-to-zero mode cannot shrink a box.
@@ -123,6 +126,48 @@ RT_HD void rt_pack_children_q8(DevNode &n, const float *blo0, const float *bhi0,
     }
     n.lox = lo[0]; n.loy = lo[1]; n.loz = lo[2];
     n.c0x = q[0]; n.c0y = q[1]; n.c0z = q[2];
+}
+
+// One 8-ary node (DevNode8): child boxes (unpadded; absent children have lo > hi) -> lower corner, per-axis scale exponents and
+// outward-rounded 8-bit plane offsets.  The masks and bases are left alone.  Needs rt_q8_fits(root box) for the scale range.
+RT_HD void rt_pack_node8(DevNode8 &n, const float (*blo)[3], const float (*bhi)[3], uint32_t present_mask) {
+    float lo[3] = {0.0f, 0.0f, 0.0f}, hi[3] = {0.0f, 0.0f, 0.0f};
+    bool any = false;
+    for (int c = 0; c < 8; c++) {
+        if (!((present_mask >> c) & 1u)) continue;
+        for (int k = 0; k < 3; k++) {
+            const float l = rt_pad_lo(blo[c][k]), h = rt_pad_hi(bhi[c][k]);
+            if (!any || l < lo[k]) lo[k] = l;
+            if (!any || h > hi[k]) hi[k] = h;
+        }
+        any = true;
+    }
+    uint32_t eb[3];
+    double inv_scale[3];
+    for (int k = 0; k < 3; k++) {
+        const double ext = (double)hi[k] - (double)lo[k];
+        int e = -126;
+        while (e < 127 && 255.0 * ldexp(1.0, e) < ext) e++;
+        eb[k] = (uint32_t)(e + 127);
+        inv_scale[k] = ldexp(1.0, -e);
+    }
+    uint32_t q[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int c = 0; c < 8; c++) {
+        const bool present = (present_mask >> c) & 1u;
+        for (int k = 0; k < 3; k++) {
+            uint32_t ql = 255u, qh = 0u;                       // absent: an inverted box
+            if (present) {
+                const double l = floor(((double)rt_pad_lo(blo[c][k]) - (double)lo[k]) * inv_scale[k]);
+                const double h = ceil(((double)rt_pad_hi(bhi[c][k]) - (double)lo[k]) * inv_scale[k]);
+                ql = l >= 0.0 && l <= 255.0 ? (uint32_t)l : (l < 0.0 ? 0u : 255u);
+                qh = h >= 0.0 && h <= 255.0 ? (uint32_t)h : (h > 255.0 ? 255u : 0u);
+            }
+            q[k][c >> 1] |= (ql << (8 * (c & 1))) | (qh << (16 + 8 * (c & 1)));
+        }
+    }
+    n.lox = lo[0]; n.loy = lo[1]; n.loz = lo[2];
+    n.exps_imask = (n.exps_imask & 0xFF000000u) | eb[0] | (eb[1] << 8) | (eb[2] << 16);
+    for (int p = 0; p < 4; p++) { n.qx[p] = q[0][p]; n.qy[p] = q[1][p]; n.qz[p] = q[2][p]; }
 }
 
 // geometry transform of one corner, the host's expression (host/bvh_builder.cpp gather_triangles): every

@@ -20,7 +20,7 @@ __device__ __forceinline__ void grow(RtRefitBox &b, const RtRefitBox &o) {
 }
 
 __global__ __launch_bounds__(256) void rt_refit_tris(DevTri *__restrict__ tris, const DevShade *__restrict__ shade,
-                                                     const float *__restrict__ xform, RtRefitBox *__restrict__ tribox, uint64_t n_slots) {
+                                                     const float *__restrict__ xform, RtRefitBox *__restrict__ tribox, uint64_t n_slots, float prim_pad) {
     const uint64_t slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (slot >= n_slots) return;
     DevTri t = tris[slot];
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void rt_refit_tris(DevTri *__restrict__ tris, 
             b.hi[k] = fmaxf(c[k], fmaxf(c[3 + k], c[6 + k]));
         }
     }
+    for (int k = 0; k < 3; k++) { b.lo[k] -= prim_pad; b.hi[k] += prim_pad; }      // as the host build widens them (rt_pack.h rt_prim_pad)
     tribox[slot] = b;
 }
 
@@ -98,11 +99,11 @@ __global__ __launch_bounds__(256) void rt_refit_nodes(float4 *__restrict__ chunk
 
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
-                           RtRefitBox *root_out, bool q8, hipStream_t stream) {
+                           RtRefitBox *root_out, bool q8, float prim_pad, hipStream_t stream) {
     if (n_slots == 0 || n_nodes == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(arrived, 0, (size_t)n_nodes * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    rt_refit_tris<<<dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream>>>(tris, shade, xform, tribox, n_slots);
+    rt_refit_tris<<<dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream>>>(tris, shade, xform, tribox, n_slots, prim_pad);
     rt_refit_nodes<<<dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream>>>(chunks, stride, parent, arrived, cbox, tribox, n_nodes, n_slots, root_out, q8 ? 1u : 0u);
     return hipGetLastError();
 }

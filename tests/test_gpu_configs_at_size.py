@@ -64,7 +64,7 @@ def _uniform(mod, cfg, w, h, samples):
                             max_bounces=cfg["max_bounces"], samples=samples)
 
 
-def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_q8):
+def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_wide):
     cfg, s = _scene(rt, name)
     n_prims = len(s.indices) // 3 + len(s.spheres)
     osc = oracle_mod.OracleScene(obj_loader.Scene(s.vertices, s.indices, s.primitives, s.models),
@@ -82,9 +82,9 @@ def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_q8):
         got, hits = ctx.accum_download(), ctx.aov_download()
     assert st.pixel_frames == w * h
     assert st.rays == cnt.rays, (st.rays, cnt.rays)
-    # the node format chosen by size (RT_OPT_NODE_FORMAT = 0): compact records once the node array exceeds 16 MB
+    # the node format chosen by size (RT_OPT_NODE_FORMAT = 0): 80-byte 8-ary nodes once the nodes would exceed 16 MB
     per_node = (st.bvh_bytes - n_prims * (48 + 128)) / st.bvh_nodes
-    assert (per_node < 48) == expect_q8, per_node
+    assert (per_node == 80) == expect_wide, per_node
     assert np.array_equal(hits, want_hits), f"{int((hits != want_hits).any(axis=-1).sum())} primary hit ids differ"
     assert_images_identical(got, want, name)
     return st
@@ -93,14 +93,14 @@ def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_q8):
 def test_c4_full_scene_matches_oracle(rt, oracle_mod, obj_loader, capsys):
     """C4: 1,059 baked teapots (9.99 M triangles) + 100,000 spheres, 160x90, 16 spp, 8 bounces."""
     with heartbeat(capsys, "C4 10M"):
-        st = _against_oracle(rt, oracle_mod, obj_loader, "C4", 160, 90, 16, expect_q8=True)
-    assert st.bvh_nodes > 4_000_000 and st.stack_entries >= 24
+        st = _against_oracle(rt, oracle_mod, obj_loader, "C4", 160, 90, 16, expect_wide=True)
+    assert st.bvh_nodes > 2_000_000 and st.stack_entries >= 16
 
 
 def test_c5q_50m_triangles_match_oracle(rt, oracle_mod, obj_loader, capsys):
     """C5q: 5,300 baked teapots (50 M triangles, > 4 GiB of device records: the 64-bit offset paths), 96x54, 4 spp."""
     with heartbeat(capsys, "C5q 50M"):
-        st = _against_oracle(rt, oracle_mod, obj_loader, "C5q", 96, 54, 4, expect_q8=True)
+        st = _against_oracle(rt, oracle_mod, obj_loader, "C5q", 96, 54, 4, expect_wide=True)
     assert st.bvh_bytes > (4 << 30)
 
 
@@ -118,7 +118,7 @@ def _c5_properties(rt):
     assert n_tris >= 199_000_000
     w, h, samples = 96, 54, 4
     images, stats = [], []
-    for fmt in (0, 1):                                   # 0: by size (compact nodes at this size), 1: 48-byte nodes
+    for fmt in (0, 1):                                   # 0: by size (8-ary nodes at this size), 1: 48-byte binary nodes
         with rt.Context(0) as ctx:
             ctx.set_option(rt.RT_OPT_NODE_FORMAT, fmt)
             ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
@@ -132,10 +132,10 @@ def _c5_properties(rt):
     assert a.rays == b.rays
     # every path has between 1 (primary miss) and max_bounces + 1 segments
     assert w * h * samples <= a.rays <= w * h * samples * (cfg["max_bounces"] + 1)
-    assert a.bvh_nodes == b.bvh_nodes and a.bvh_nodes >= n_tris // 8
-    assert a.bvh_bytes < b.bvh_bytes                      # the compact format was chosen by size
-    assert 2 <= a.stack_entries <= 48 and a.stack_entries == b.stack_entries
+    assert n_tris // 8 <= a.bvh_nodes < b.bvh_nodes       # the 8-ary format was chosen by size: fewer, wider nodes
+    assert a.bvh_bytes < b.bvh_bytes
+    assert 2 <= a.stack_entries <= 40 and 2 <= b.stack_entries <= 48
     assert np.isfinite(img[..., :3]).all() and (img[..., :3] >= 0).all() and (img[..., :3] <= 1).all()   # tone-mapped (main.wgsl:117)
     assert (img[..., 3] == 0).all()                       # the pad lane of array<vec3f> is never written
     assert img[..., :3].max() > 0.05                      # not a black frame
-    assert_images_identical(images[0], images[1], "C5: compact vs 48-byte nodes")
+    assert_images_identical(images[0], images[1], "C5: 8-ary vs 48-byte binary nodes")

@@ -1,0 +1,44 @@
+"""
+The 8-ary node format (RT_OPT_NODE_FORMAT = 3, DevNode8) is chosen automatically only for scenes with millions of
+primitives (tests/test_gpu_configs_at_size.py).  Here the WHOLE GPU parity suite — every scene, kernel variant, material,
+sphere / texture / refit / sharding / multi-frame case of test_gpu_parity.py, test_textures.py and test_gpu_group.py —
+is run once more in a child process whose contexts default to that format (RT_AMD_NODE_FORMAT=3), so the wide format is
+held to the same bit-exact bar as the binary ones on all of them.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.skipif(os.environ.get("RT_AMD_NODE_FORMAT") is not None, reason="already the child run")
+def test_parity_suite_on_8ary_nodes():
+    env = dict(os.environ, RT_AMD_NODE_FORMAT="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "tests/test_gpu_parity.py", "tests/test_textures.py", "tests/test_gpu_group.py", "tests/test_zz_no_alloc.py"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    tail = r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+def test_8ary_format_is_really_used(rt, scenes):
+    """Guards the test above against passing on a silent fallback: with format 3 the tree has 80-byte nodes and far fewer of them."""
+    from conftest import config
+    s = scenes("teapot-circle")
+    sizes = {}
+    for fmt in (1, 3):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.RT_OPT_NODE_FORMAT, fmt)
+            ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+            st = ctx.stats()
+            n_prims = len(s.indices) // 3
+            sizes[fmt] = (st.bvh_nodes, (st.bvh_bytes - n_prims * (48 + 128)) / st.bvh_nodes, st.stack_entries)
+    assert sizes[1][1] == 48 and sizes[3][1] == 80
+    assert sizes[3][0] < sizes[1][0] / 1.8
+    assert sizes[3][2] <= 24

@@ -1,0 +1,15 @@
+#!/bin/bash
+# How sensitive is the render kernel to extra VALU work / extra node fetches?  Builds variants of librt_amd.so with dummy
+# instructions (-DRT_EXP_*) into tools/sens/, to be timed with bench.py through RT_AMD_LIB.  CPU only (cross-compile).
+cd "$(dirname "$0")/../ray-tracing_amd" || exit 1
+mkdir -p ../tools/sens
+for v in "base:" "nv12:-DRT_EXP_NODE_VALU=12" "nv24:-DRT_EXP_NODE_VALU=24" "nl1:-DRT_EXP_NODE_LOAD=1" "sv80:-DRT_EXP_SHADE_VALU=80" "sv160:-DRT_EXP_SHADE_VALU=160"; do
+  name=${v%%:*}; flag=${v#*:}
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function --offload-arch=gfx950 \
+    -fhip-fp32-correctly-rounded-divide-sqrt -Xarch_host -mfma $flag -fno-slp-vectorize -mllvm -structurizecfg-skip-uniform-regions=1 \
+    -c csrc/rt_kernels.hip -o ../tools/sens/k_$name.o || exit 1
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../tools/sens/librt_$name.so ../tools/sens/k_$name.o build/rt_refit.o build/rt_capture.o build/rt_api.o \
+    build/scene_loader.o build/bvh_builder.o build/capture.o build/app.o build/image_decode.o build/host_api.o -lpthread -lz || exit 1
+done
+rm -f ../tools/sens/*.o
+ls -la ../tools/sens
