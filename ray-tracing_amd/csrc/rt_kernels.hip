@@ -801,7 +801,9 @@ __global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
         if (c_leaf * P.tune[1] > best_c) { pick = PH_LEAF; best_c = c_leaf * P.tune[1]; }
         if (c_shade * P.tune[2] > best_c) { pick = PH_SHADE; best_c = c_shade * P.tune[2]; }
         if (c_fetch * P.tune[4] > best_c) { pick = PH_FETCH; }
-        return pick;
+        // wave-uniform by construction (ballot counts, kernel arguments); said explicitly because the file is built with
+        // -structurizecfg-skip-uniform-regions, which keeps branches on uniform values scalar
+        return __builtin_amdgcn_readfirstlane(pick);
     };
 
 #ifdef RT_TAIL_PROBE

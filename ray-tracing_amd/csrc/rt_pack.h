@@ -14,7 +14,10 @@ RT_HD float rt_pad_lo(float v) { return v - (fabsf(v) * 4.76837158e-7f + 1e-30f)
 RT_HD float rt_pad_hi(float v) { return v + (fabsf(v) * 4.76837158e-7f + 1e-30f); }
 
 // Absolute widening of every PRIMITIVE's box, from the scene's largest |coordinate| (see rt_api.hip host_build)
-RT_HD float rt_prim_pad(float scene_max_abs) { return scene_max_abs <= 3.0e38f ? scene_max_abs * 7.62939453125e-6f : 0.0f; }   // 2^-17
+#ifndef RT_PRIM_PAD_SCALE
+#define RT_PRIM_PAD_SCALE 7.62939453125e-6f   /* 2^-17 */
+#endif
+RT_HD float rt_prim_pad(float scene_max_abs) { return scene_max_abs <= 3.0e38f ? scene_max_abs * RT_PRIM_PAD_SCALE : 0.0f; }
 
 // x >= 0 → the f16 bit pattern nearest to x from below (up = false) or above (up = true).
 // Above saturates to +inf, below to 65504; a non-zero upper bound is never an f16
