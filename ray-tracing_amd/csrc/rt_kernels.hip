@@ -801,9 +801,11 @@ __global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
         if (c_leaf * P.tune[1] > best_c) { pick = PH_LEAF; best_c = c_leaf * P.tune[1]; }
         if (c_shade * P.tune[2] > best_c) { pick = PH_SHADE; best_c = c_shade * P.tune[2]; }
         if (c_fetch * P.tune[4] > best_c) { pick = PH_FETCH; }
-        // wave-uniform by construction (ballot counts, kernel arguments); said explicitly because the file is built with
-        // -structurizecfg-skip-uniform-regions, which keeps branches on uniform values scalar
-        return __builtin_amdgcn_readfirstlane(pick);
+        // wave-uniform by construction: ballot counts (s_bcnt1 of lane masks) and kernel arguments only, all in SGPRs.  The file
+        // is built with -structurizecfg-skip-uniform-regions, which keeps branches on such values scalar.
+        // (An explicit readfirstlane here was tried: it moves the value through a VGPR and the kernel then needs 96 VGPRs with
+        // 80 bytes of scratch instead of 78 and none.)
+        return pick;
     };
 
 #ifdef RT_TAIL_PROBE
