@@ -277,22 +277,23 @@ def main():
                                                "tris_per_ray": model["tris_per_ray"], "hit_fraction": model["hit_fraction"], "byte_model": model_src,
                                                "note": "SURVEY section 8(d) model: 32 B per box test, 36 B per triangle test, 284 B per hit, 32 B per pixel-frame; "
                                                        "above 1 means the records are cache-resident and these bytes never reach HBM"}}
-            # On-chip ceilings at the kernel's own instruction counts (profiles/onchip.json, reduced from the PMC passes of
-            # the same command by tools/pmc_summary.py): VALU issue = 1024 SIMDs x clock / 4 clocks per wave64 instruction /
-            # wave-instructions per ray; L1 = lane-loads per clock per CU (tools/microbench/gather_width.hip) x 256 CUs x clock
-            # / lane-loads per ray.  The lower one binds.
+            # The on-chip ceiling that binds (profiles/onchip.json, reduced from the PMC passes of the same command by
+            # tools/pmc_summary.py): the L1 path = tag look-ups per clock per CU (tools/microbench/gather_width.hip) x 256 CUs x
+            # clock / the kernel's tag look-ups per ray.
             opath = os.path.join(ROOT, "profiles", "onchip.json")
             if os.path.exists(opath):
                 oc = json.load(open(opath)).get(args.config)
                 if oc:
                     achieved_mrays = rays / launches / world / (kernel_ms * 1e-3) / 1e6
-                    valu = N_SIMD * CLOCK_HZ / 4.0 / oc["valu_wave_insts_per_ray"] / 1e6
-                    l1 = oc["l1_lane_loads_per_clk_per_cu"] * 256 * CLOCK_HZ / oc["lane_loads_per_ray"] / 1e6
-                    name, ceil = ("valu_issue", valu) if valu <= l1 else ("l1_lane_loads", l1)
-                    out["roofline"]["onchip"] = {"bound": name, "ceiling_mrays": ceil, "achieved_mrays": achieved_mrays, "frac": achieved_mrays / ceil,
-                                                 "valu_issue_ceiling_mrays": valu, "l1_lane_load_ceiling_mrays": l1,
-                                                 "valu_wave_insts_per_ray": oc["valu_wave_insts_per_ray"], "lane_loads_per_ray": oc["lane_loads_per_ray"],
-                                                 "valu_lane_utilization": oc.get("valu_lane_utilization"), "clock_hz": CLOCK_HZ, "profile": oc.get("profile")}
+                    l1 = oc["l1_tag_lookups_per_clk_per_cu_peak"] * 256 * CLOCK_HZ / oc["l1_tag_lookups_per_ray"] / 1e6
+                    out["roofline"]["onchip"] = {"bound": "l1_tag_lookups", "ceiling_mrays": l1, "achieved_mrays": achieved_mrays, "frac": achieved_mrays / l1,
+                                                 "l1_tag_lookups_per_ray": oc["l1_tag_lookups_per_ray"], "l1_tag_lookups_per_clk_per_cu_peak": oc["l1_tag_lookups_per_clk_per_cu_peak"],
+                                                 "valu_wave_insts_per_ray": oc["valu_wave_insts_per_ray"], "valu_insts_per_simd_clk_in_profile": oc.get("measured_valu_insts_per_simd_clk"),
+                                                 "valu_lane_utilization": oc.get("valu_lane_utilization"), "clock_hz": CLOCK_HZ, "profile": oc.get("profile"),
+                                                 "note": "ceiling = 256 CUs x clock x 1.5 L1 tag look-ups per clock per CU (tools/microbench/gather_width.hip: divergent lane-loads "
+                                                         "that hit L1, any width up to 16 B) / the kernel's own look-ups per ray (profiles/onchip.json).  The VALU pipes issue "
+                                                         "at their nominal rate too (0.25 wave64 instructions per clock per SIMD), but dummy-instruction builds show the time "
+                                                         "follows fetches, not VALU work (DESIGN.md section 5)"}
         print(json.dumps(out), flush=True)
 
     if args.verify and rank == 0:

@@ -3,7 +3,9 @@
 # Usage: bash profiles/run_pmc_extra.sh <tag> [config] [steps]
 set -u
 TAG=${1:-x}; CONFIG=${2:-C3}; STEPS=${3:-8}
+OPTS=${4:-}
 OUT=$PWD/gpurun_out/prof_$TAG; mkdir -p "$OUT"; export TMPDIR=/tmp
+[ -n "$OPTS" ] && export RT_BENCH_OPTIONS=$OPTS
 CMD="python3 bench.py --config $CONFIG --steps $STEPS --warmup $STEPS --no-cpu"
 for pass in "TA_BUSY_avr TA_TA_BUSY_sum TD_TD_BUSY_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE" \
             "TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \

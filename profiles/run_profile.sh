@@ -5,11 +5,13 @@ set -u
 TAG=${1:-r1}
 CONFIG=${2:-C3}
 STEPS=${3:-8}
+OPTS=${4:-}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # warm-up = steps: rt_dispatch_frames folds a run of frames into ONE launch, so both launches are the same size
 # and rocprofv3's per-kernel average is the duration of a $STEPS-frame launch
+[ -n "$OPTS" ] && export RT_BENCH_OPTIONS=$OPTS
 CMD="python3 bench.py --config $CONFIG --steps $STEPS --warmup $STEPS --no-cpu"
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum" \

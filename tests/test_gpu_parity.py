@@ -416,7 +416,7 @@ def test_bench_contract_and_sharded_image(ranks):
         assert key in m["roofline"]
     assert 0.0 < m["roofline"]["frac"] <= 1.0          # measured HBM traffic against the HBM peak: a fraction that can bind
     if "onchip" in m["roofline"]:
-        assert 0.0 < m["roofline"]["onchip"]["frac"] <= 1.05
+        assert 0.0 < m["roofline"]["onchip"]["frac"] <= 1.0
     if ranks == 1:                                   # the CPU leg runs on rank 0 at N = 1 only
         assert m["cpu_baseline"]["kind"] == "port" and m["cpu_baseline"]["value"] > 0
         assert 1 <= m["cpu_baseline"]["cores"] <= (os.cpu_count() or 1) and m["cpu_baseline"]["cpu_model"]
