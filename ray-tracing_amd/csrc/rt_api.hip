@@ -35,6 +35,10 @@ hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xfo
                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
                            RtRefitBox *root_out, bool q8, float prim_pad, hipStream_t stream);
 
+hipError_t rt_launch_refit8(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
+                            uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
+                            RtRefitBox *root_out, float prim_pad, hipStream_t stream);
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -107,6 +111,7 @@ struct rt_context {
     uint64_t n_nodes = 0, n_tris = 0, node_bytes = 0;
     uint32_t stack_entries = 1;
     float scene_abs[3] = {0.0f, 0.0f, 0.0f};
+    float prim_pad_scale = 0.0f;     // the scene scale the last host build widened the primitives' boxes by (rt_prim_pad)
     bool have_scene = false;
     bool last_update_on_device = false;   // rt_models_update: the last call was served by device_refit alone
     bool models_committed = false;   // the last build_and_upload / device_refit got as far as changing device state
@@ -221,6 +226,7 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
     for (const auto &n : bvh.nodes) if (n.count == 0) n_inner2++;
     out.nodes8.assign(n_inner2 + 1, DevNode8());
     memset(out.nodes8.data(), 0, out.nodes8.size() * sizeof(DevNode8));
+    out.parent.assign(n_inner2 + 1, -1);                 // node -> parent * 8 + child slot (device refit)
     std::atomic<uint64_t> next_node{1}, next_slot{0};
     std::atomic<uint32_t> max_depth{0};
     struct Item { uint32_t src, dst, depth; };
@@ -313,7 +319,10 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
         for (int s8 = 0; s8 < 8; s8++) {
             const int i = child_at[s8];
             if (i < 0) continue;
-            if (ch[i].inner) todo.push_back({ch[i].ref, (uint32_t)(base + ki++), it.depth + 1});
+            if (ch[i].inner) {
+                out.parent[base + ki] = (int32_t)(it.dst * 8u + (uint32_t)s8);
+                todo.push_back({ch[i].ref, (uint32_t)(base + ki++), it.depth + 1});
+            }
             else out.order8[slot0 + kl++] = ch[i].ref;
         }
         uint32_t cur = max_depth.load(std::memory_order_relaxed);
@@ -344,6 +353,7 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
         for (auto &t : th) t.join();
     }
     out.nodes8.resize(next_node.load());
+    out.parent.resize(out.nodes8.size());
     // a path pushes at most one two-word group per level below the root (+1 spare)
     out.stack_entries = 2u * (max_depth.load() + 2u);
 }
@@ -496,6 +506,7 @@ struct Built {
     std::vector<uint8_t> packed_nodes;   // the node array as it is uploaded (restrided when node_stride != RT_NODE_CHUNKS)
     uint64_t n_prims = 0;
     double build_seconds = 0.0;
+    float prim_pad_scale = 0.0f;
 };
 
 // Host half: validate, gather triangles, build (or refit) the BVH2 in ctx->hs, repack it.  Touches no device state.
@@ -569,6 +580,7 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
             scene_r = fminf(scene_r, fmaxf(spread, scene_r * 0.015625f));
         }
         const float pad = rt_prim_pad(scene_r);
+        out.prim_pad_scale = scene_r;
         for (uint64_t i = 0; i < n_prims && scene_finite; i++)
             for (int k = 0; k < 3; k++) { boxes[i].lo[k] -= pad; boxes[i].hi[k] += pad; }
         for (int k = 0; k < 3 && scene_finite; k++) { scene_box.lo[k] -= pad; scene_box.hi[k] += pad; }
@@ -635,6 +647,7 @@ int device_upload(rt_context *ctx, const Built &b) {
     const std::vector<DevMaterial> &mats = b.mats;
     const uint64_t n_prims = b.n_prims;
     ctx->build_seconds = b.build_seconds;
+    ctx->prim_pad_scale = b.prim_pad_scale;
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     ctx->models_committed = true;    // from here on the device scene is being replaced
@@ -655,11 +668,11 @@ int device_upload(rt_context *ctx, const Built &b) {
     ctx->node_stride = rp.node_stride;
     ctx->node_q8 = rp.q8;
     dev_free(ctx->d_parent); dev_free(ctx->d_arrived); dev_free(ctx->d_cbox); dev_free(ctx->d_tribox); dev_free(ctx->d_root); dev_free(ctx->d_xform);
-    if (ctx->opt_refit == 2 && !rp.wide && rp.refit_sources_agree && rp.parent.size() == rp.nodes.size() && rp.nodes.size() > 1) {
-        const size_t nn = rp.nodes.size();
+    if (ctx->opt_refit == 2 && rp.refit_sources_agree && rp.parent.size() == n_nodes && (rp.wide || n_nodes > 1)) {
+        const size_t nn = n_nodes;
         RT_HIP(hipMalloc((void **)&ctx->d_parent, nn * sizeof(int32_t)));
         RT_HIP(hipMalloc((void **)&ctx->d_arrived, nn * sizeof(unsigned int)));
-        RT_HIP(hipMalloc((void **)&ctx->d_cbox, 2 * nn * sizeof(RtRefitBox)));
+        RT_HIP(hipMalloc((void **)&ctx->d_cbox, (rp.wide ? 8 : 2) * nn * sizeof(RtRefitBox)));
         RT_HIP(hipMalloc((void **)&ctx->d_tribox, rp.tris.size() * sizeof(RtRefitBox)));
         RT_HIP(hipMalloc((void **)&ctx->d_root, sizeof(RtRefitBox)));
         RT_HIP(hipMalloc((void **)&ctx->d_xform, (ctx->hs->primitives.size() ? ctx->hs->primitives.size() : 1) * 12 * sizeof(float)));
@@ -867,9 +880,14 @@ int device_refit(rt_context *ctx) {
         RT_HIP(hipMemcpyAsync(ctx->d_xform, resolved.data(), resolved.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
         xform = ctx->d_xform;
     }
+    const float prim_pad = rt_prim_pad(ctx->prim_pad_scale);
+    if (ctx->node_wide)
+        RT_HIP(rt_launch_refit8(ctx->d_tris, ctx->d_shade, xform, ctx->d_tribox, ctx->n_tris, reinterpret_cast<float4 *>(ctx->d_nodes), ctx->node_stride,
+                                ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, prim_pad, ctx->stream));
+    else
     RT_HIP(rt_launch_refit(ctx->d_tris, ctx->d_shade, xform, ctx->d_tribox, ctx->n_tris, reinterpret_cast<float4 *>(ctx->d_nodes), ctx->node_stride,
                            ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, ctx->node_q8,
-                           rt_prim_pad(fmaxf(ctx->scene_abs[0], fmaxf(ctx->scene_abs[1], ctx->scene_abs[2]))), ctx->stream));
+                           prim_pad, ctx->stream));
     RtRefitBox root;
     RT_HIP(hipMemcpyAsync(&root, ctx->d_root, sizeof root, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));                   // also keeps `mats` / `resolved` alive long enough
@@ -879,7 +897,7 @@ int device_refit(rt_context *ctx) {
     }
     ctx->refits++;
     ctx->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (ctx->node_q8) {
+    if (ctx->node_q8 || ctx->node_wide) {
         // the moved scene may have outgrown what 8-bit offsets can span (their outward rounding saturates there):
         // rebuild on the host, which chooses the node format again
         if (!rt_q8_fits(root.lo, root.hi)) return build_and_upload(ctx, true);
@@ -1082,7 +1100,7 @@ int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_model
     // device refit: same primitives, same tree, same model ranges, the sphere -> model references still valid and the
     // material array as uploaded has room for the new models
     ctx->last_update_on_device = false;
-    if (ctx->opt_refit == 2 && ctx->d_parent && ctx->n_nodes > 1 && ranges_kept && spheres_ok && n_models <= ctx->materials_capacity) {
+    if (ctx->opt_refit == 2 && ctx->d_parent && (ctx->n_nodes > 1 || ctx->node_wide) && ranges_kept && spheres_ok && n_models <= ctx->materials_capacity) {
         const uint64_t rebuilds_before = ctx->rebuilds, refits_before = ctx->refits;
         r = device_refit(ctx);
         ctx->last_update_on_device = r == RT_OK && ctx->rebuilds == rebuilds_before && ctx->refits == refits_before + 1;

@@ -632,7 +632,7 @@ def test_uniform_fields_are_honoured(rt, oracle_mod, oracle_scenes, ctxs, kw):
     assert np.array_equal(rgb.reshape(-1, 3), oracle_mod.capture_rgb8(want)) and np.array_equal(rgb.reshape(-1, 3), rt.capture_rgb8(got))
 
 
-@pytest.mark.parametrize("node_format", [1, 2])
+@pytest.mark.parametrize("node_format", [1, 2, 3])
 def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes, node_format):
     """RT_OPT_REFIT = 2: rt_models_update recomputes the triangle records and the node boxes ON the device
     (csrc/rt_refit.hip).  Same hit ids and image as the oracle for the moved geometry and as the host refit,
@@ -655,7 +655,7 @@ def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes, node_for
     with rt.Context(0) as dev, rt.Context(0) as host:
         for ctx, mode in ((dev, 2), (host, 1)):
             ctx.set_option(rt.RT_OPT_REFIT, mode)                       # before the upload: it keeps the topology on the device
-            ctx.set_option(rt.RT_OPT_NODE_FORMAT, node_format)          # 48-byte / 32-byte node records
+            ctx.set_option(rt.RT_OPT_NODE_FORMAT, node_format)          # 48-byte / 32-byte binary nodes, 80-byte 8-ary nodes
             ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)   # no transforms at upload
             ctx.set_option(rt.RT_OPT_AOV, 1)
         for k, m in enumerate(moves):
