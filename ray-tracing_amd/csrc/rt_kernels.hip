@@ -848,6 +848,18 @@ __global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                     const float4 *n = nodes + cur;
                     float n0, n1, f0, f1;
                     int2 refs;
+#ifdef RT_EXP_NODE_VALU      // sensitivity builds (tools/sensitivity.sh): N extra dependent VALU instructions per node step
+                    { float dmy = ix;
+#pragma unroll
+                      for (int q = 0; q < RT_EXP_NODE_VALU; q++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dmy));
+                    }
+#endif
+#ifdef RT_EXP_NODE_LOAD      // sensitivity builds: N extra 16-byte fetches of the node's own first chunk (same cache line)
+                    {
+#pragma unroll
+                      for (int q = 0; q < RT_EXP_NODE_LOAD; q++) { float4 dmy; asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(dmy) : "v"(n) : "memory"); }
+                    }
+#endif
                     // rotate amounts: bits 4:0 of the stuffed inverse (see start_trace), 16 for a negative direction
                     const uint32_t rx = __float_as_uint(ix), ry = __float_as_uint(iy), rz = __float_as_uint(iz);
                     if (Q8) {
@@ -955,6 +967,12 @@ __global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                 // new pixel whose first path starts here, where more lanes share the work than at the pixel boundary
                 const bool fresh = S.bounce == kFreshPixel;
                 bool more = true, next_sample = fresh;
+#ifdef RT_EXP_SHADE_VALU     // sensitivity builds: N extra dependent VALU instructions per shade step
+                { float dmy = ix;
+#pragma unroll
+                  for (int q = 0; q < RT_EXP_SHADE_VALU; q++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dmy));
+                }
+#endif
                 if (!fresh) {
                     tl.rays++;
                     if (shade_core<AOV, SPH, LDSM>(P, S, best)) {
