@@ -360,9 +360,11 @@ def test_full_size_c3_frame_properties(rt, ctxs):
     assert np.abs(again - img).max() <= 6e-8
 
 
-def test_headless_cli_capture_matches_oracle(rt, oracle_mod, oracle_scenes, tmp_path):
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_headless_cli_capture_matches_oracle(rt, oracle_mod, oracle_scenes, tmp_path, devices):
     """rt_cli = the reference's frame loop (src/app.rs:74-102) + Capture (src/ui.rs:78-94), headless: its PNG
-    must hold exactly the oracle's accumulation buffer pushed through `(x*255) as u8`."""
+    must hold exactly the oracle's accumulation buffer pushed through `(x*255) as u8`.  With --devices the C++ host drives
+    an rt_group (three shards on the one GPU here) through the same calls: same PNG."""
     import struct
     import subprocess
     import zlib
@@ -372,7 +374,8 @@ def test_headless_cli_capture_matches_oracle(rt, oracle_mod, oracle_scenes, tmp_
     exe = os.path.join(ROOT, "ray-tracing_amd", "rt_cli")
     pos = ",".join(str(v) for v in cfg["position"])
     r = subprocess.run([exe, "--scene", scene_path("cornell-box"), "--size", f"{w}x{h}", "--samples", str(spp), "--frames", str(frames),
-                        "--bounces", str(cfg["max_bounces"]), "--pos", pos, "--yaw", repr(cfg["yaw"]), "--pitch", "0", "--out", out],
+                        "--bounces", str(cfg["max_bounces"]), "--pos", pos, "--yaw", repr(cfg["yaw"]), "--pitch", "0", "--out", out]
+                       + (["--devices", devices] if devices else []),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     accum, _ = oracle_scenes("cornell-box").render_frames(uniforms_for(oracle_mod, cfg, w, h, samples=spp), frames, mode=1)
