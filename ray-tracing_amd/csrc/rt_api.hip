@@ -354,8 +354,10 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
     }
     out.nodes8.resize(next_node.load());
     out.parent.resize(out.nodes8.size());
-    // a path pushes at most one two-word group per level below the root (+1 spare)
-    out.stack_entries = 2u * (max_depth.load() + 2u);
+    // When a node at depth d is visited the stack holds at most d groups (one may be pushed each time a child is taken from a
+    // group with siblings left; the root is the only child of a virtual group and pushes nothing), and primitives push nothing:
+    // 2 words x the depth of the deepest node, exactly.  (Every KiB counts: C5 fits 5 workgroups per CU at 26 words, 4 at 30.)
+    out.stack_entries = std::max(2u, 2u * max_depth.load());
 }
 
 void repack(const rt_host::Bvh2 &bvh, const std::vector<float> &corners, const std::vector<uint32_t> &ids,
@@ -808,8 +810,14 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
         if (ctx->persistent_blocks == 0 || ctx->persistent_sel != sel) {
             ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm, ctx->node_wide ? 2 : (ctx->node_q8 ? 1 : 0));
             ctx->persistent_sel = sel;
-            if (ctx->tune[3] > 0 && ctx->cu_count > 0 && ctx->persistent_blocks > ctx->tune[3] * ctx->cu_count)
-                ctx->persistent_blocks = ctx->tune[3] * ctx->cu_count;       // developer knob 103: workgroups per CU
+            // Resident workgroups per CU.  More waves hide more latency only while their rays' working set stays in the caches and the
+            // TLB; measured (8-ary nodes, ms per step at 3 / 4 / 5 workgroups): C4, 2 GB of records: 126 / 109 / 102; C5q, 10 GB:
+            // 64.7 / 58.5 / 63.8; C5, 39 GB: 509 / 574 / 698.  Hence by size, unless knob 103 says otherwise.
+            const uint64_t record_bytes = ctx->node_bytes + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));
+            int per_cu = ctx->tune[3];
+            if (per_cu <= 0) per_cu = record_bytes > (20ull << 30) ? 3 : (record_bytes > (4ull << 30) ? 4 : 0);
+            if (per_cu > 0 && ctx->cu_count > 0 && ctx->persistent_blocks > per_cu * ctx->cu_count)
+                ctx->persistent_blocks = per_cu * ctx->cu_count;
         }
     }
 #ifdef RT_TAIL_PROBE
