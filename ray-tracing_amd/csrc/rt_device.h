@@ -125,7 +125,9 @@ struct RtGatherLayout {
 // Material records (64 B each) the phased kernel copies into LDS at its start when the scene has no more than this
 // many: the L1 path is the busiest unit of that kernel and LDS is nearly idle.  Scenes with more read them from memory.
 #define RT_TOP_NODES 64u                 // nodes the host numbers breadth-first at the start of the node array (the levels every ray walks share cache lines)
+#ifndef RT_LDS_MATERIALS
 #define RT_LDS_MATERIALS 16u
+#endif
 
 struct RenderParams {
     const DevNode *nodes;

@@ -835,6 +835,18 @@ __global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                                 else { sptr[0] = ng_base; sptr[kBlock] = ng_mask; sptr += 2 * kBlock; }
                             }
                             if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
+#ifdef RT_EXP_NODE_VALU      // sensitivity builds (tools/sensitivity.sh)
+                            { float dmy = ix;
+#pragma unroll
+                              for (int q = 0; q < RT_EXP_NODE_VALU; q++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dmy));
+                            }
+#endif
+#ifdef RT_EXP_NODE_LOAD
+                            {
+#pragma unroll
+                              for (int q = 0; q < RT_EXP_NODE_LOAD; q++) { float4 dmy; asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(dmy) : "v"(nodes + node) : "memory"); }
+                            }
+#endif
                             uint32_t imask, lmask;
                             const uint32_t h = test_node8(nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
                             ng_mask = (h & imask) | (imask << 8);
