@@ -185,15 +185,18 @@ typedef struct RtStats {
                                       1 refit on the host and upload everything; 0 full rebuild */
 #define RT_OPT_FRAME_PIPELINE  7   /* 1 (default): rt_dispatch_frames renders its frames in one launch, frames of
                                       different pixels overlapping (same bits as frame-by-frame); 0: one launch per frame */
-#define RT_OPT_NODE_STRIDE     6   /* BVH node stride in 16-byte units for the NEXT scene upload: 3 (48 B, tightest),
-                                      4 (64 B, one memory sector per node) or 0 (default = 3) */
+#define RT_OPT_NODE_STRIDE     6   /* BVH node stride in 16-byte units for the NEXT scene upload: binary 48-byte nodes 3 (tightest) or 4
+                                      (one 64-byte sector per node); 80-byte 8-ary nodes 8 (one 128-byte line per node); 0 = packed */
 
-#define RT_OPT_NODE_FORMAT     8   /* BVH node record of the NEXT scene upload: 1 = 48 bytes (f16 plane offsets, three 16-byte
-                                      fetches per visit), 2 = 32 bytes (8-bit offsets and a per-node power-of-two scale, two
-                                      fetches; needs a scene extent <= 2^18, else 48-byte
-                                      nodes are used all the same), 0 (default) = 32 bytes when they fit and the nodes exceed
-                                      16 MB (they then miss the caches and the smaller record wins), else 48.  Both are
-                                      conservative: same image bits. */
+#define RT_OPT_NODE_FORMAT     8   /* BVH node record of the NEXT scene upload.  All formats are conservative: same image bits.
+                                      1 = 48-byte binary nodes (f16 plane offsets, three 16-byte fetches for two boxes);
+                                      2 = 32-byte binary nodes (8-bit offsets and a per-node power-of-two scale, two fetches);
+                                      3 = 80-byte 8-ary nodes (8-bit offsets, per-axis scales, one primitive per leaf child, octant-ordered
+                                          traversal with a two-word group stack: five fetches for eight boxes);
+                                      4 = 64-byte 8-ary nodes (the same tree; the corner is three 14-bit cells of a per-scene grid:
+                                          four fetches and one 64-byte line per visit);
+                                      0 (default) = by size: 48-byte binary nodes while the nodes stay in the caches, 64-byte 8-ary
+                                          nodes once they would exceed ~16 MB.  Formats 2-4 need a scene extent <= 2^18 (else 1 is used). */
 
 typedef struct rt_context rt_context;
 

@@ -37,7 +37,7 @@ hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xfo
 
 hipError_t rt_launch_refit8(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                             uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
-                            RtRefitBox *root_out, float prim_pad, hipStream_t stream);
+                            RtRefitBox *root_out, float prim_pad, const float *grid_lo_cell, hipStream_t stream);
 
 namespace {
 
@@ -148,7 +148,9 @@ struct rt_context {
     int opt_node_stride = 0;
     int opt_node_format = 0;         // RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte nodes, 2 32-byte q8 nodes
     bool node_q8 = false;            // format of the nodes on the device
-    bool node_wide = false;          // 80-byte 8-ary nodes (RT_OPT_NODE_FORMAT 3)
+    bool node_wide = false;          // 8-ary nodes (RT_OPT_NODE_FORMAT 3 / 4)
+    bool node_compact = false;       // ... in 64-byte records (DevNode8c, format 4) with their corner grid
+    float grid_lo[3] = {0.0f, 0.0f, 0.0f}, grid_cell[3] = {1.0f, 1.0f, 1.0f};
     // the 8-ary format is traversed by every kernel variant
     bool opt_kernel_wide_ok() const { return true; }
     int opt_kernel = 2;
@@ -190,6 +192,9 @@ struct Repacked {
     bool q8 = false;                 // 32-byte records (rt_pack.h), node_stride 2
     bool wide = false;               // 80-byte 8-ary nodes (DevNode8) in `nodes8`, node_stride 5
     std::vector<DevNode8> nodes8;
+    bool compact = false;            // wide: 64-byte records (DevNode8c) in `nodes8c`, node_stride 4
+    std::vector<DevNode8c> nodes8c;
+    float grid_lo[3] = {0.0f, 0.0f, 0.0f}, grid_cell[3] = {1.0f, 1.0f, 1.0f};   // compact: the corner grid (rt_pack.h rt_grid_for)
     std::vector<uint32_t> order8;    // wide: slot -> primitive id (a node's leaf children are consecutive slots)
     std::vector<int32_t> parent;     // node -> parent * 2 + child slot (device refit)
     bool refit_sources_agree = true; // shading-record corners == BLAS corners (see repack)
@@ -224,8 +229,13 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
     out.order8.assign(n_prims, 0u);
     uint64_t n_inner2 = 0;
     for (const auto &n : bvh.nodes) if (n.count == 0) n_inner2++;
-    out.nodes8.assign(n_inner2 + 1, DevNode8());
-    memset(out.nodes8.data(), 0, out.nodes8.size() * sizeof(DevNode8));
+    if (out.compact) {
+        out.nodes8c.assign(n_inner2 + 1, DevNode8c());
+        memset(out.nodes8c.data(), 0, out.nodes8c.size() * sizeof(DevNode8c));
+    } else {
+        out.nodes8.assign(n_inner2 + 1, DevNode8());
+        memset(out.nodes8.data(), 0, out.nodes8.size() * sizeof(DevNode8));
+    }
     out.parent.assign(n_inner2 + 1, -1);                 // node -> parent * 8 + child slot (device refit)
     std::atomic<uint64_t> next_node{1}, next_slot{0};
     std::atomic<uint32_t> max_depth{0};
@@ -309,12 +319,18 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
         }
         const uint64_t base = n_inner ? next_node.fetch_add(n_inner, std::memory_order_relaxed) : 0;
         const uint64_t slot0 = n_leaf ? next_slot.fetch_add(n_leaf, std::memory_order_relaxed) : 0;
-        DevNode8 &d = out.nodes8[it.dst];
-        d.exps_imask = imask << 24;
-        d.lmask = lmask;
-        d.child_base = (uint32_t)(base * out.node_stride);
-        d.tri_base = (uint32_t)slot0;
-        rt_pack_node8(d, blo, bhi, imask | lmask);
+        if (out.compact) {
+            DevNode8c &d = out.nodes8c[it.dst];
+            rt_node8c_set_links(d, imask, lmask, (uint32_t)base, (uint32_t)slot0);
+            rt_pack_node8c(d, blo, bhi, imask | lmask, out.grid_lo, out.grid_cell);
+        } else {
+            DevNode8 &d = out.nodes8[it.dst];
+            d.exps_imask = imask << 24;
+            d.lmask = lmask;
+            d.child_base = (uint32_t)(base * out.node_stride);
+            d.tri_base = (uint32_t)slot0;
+            rt_pack_node8(d, blo, bhi, imask | lmask);
+        }
         uint32_t ki = 0, kl = 0;
         for (int s8 = 0; s8 < 8; s8++) {
             const int i = child_at[s8];
@@ -352,8 +368,8 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
         worker();
         for (auto &t : th) t.join();
     }
-    out.nodes8.resize(next_node.load());
-    out.parent.resize(out.nodes8.size());
+    if (out.compact) out.nodes8c.resize(next_node.load()); else out.nodes8.resize(next_node.load());
+    out.parent.resize(next_node.load());
     // When a node at depth d is visited the stack holds at most d groups (one may be pushed each time a child is taken from a
     // group with siblings left; the root is the only child of a virtual group and pushes nothing), and primitives push nothing:
     // 2 words x the depth of the deepest node, exactly.  (Every KiB counts: C5 fits 5 workgroups per CU at 26 words, 4 at 30.)
@@ -593,7 +609,9 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     // (five fetches for eight boxes, 30 visits per ray instead of 67 on C4: 100.6 vs 110.2 ms per step with 32-byte binary nodes).
     // A BVH2 over n primitives with leaves of ~2 has ~n inner nodes of 48 bytes.
     const bool big = n_prims * sizeof(DevNode) / 2 >= (16ull << 20);
-    const bool wide = fits && ctx->opt_kernel_wide_ok() && (ctx->opt_node_format == 3 || (ctx->opt_node_format == 0 && big));
+    const bool wide = fits && ctx->opt_kernel_wide_ok() && (ctx->opt_node_format == 3 || ctx->opt_node_format == 4 || (ctx->opt_node_format == 0 && big));
+    // 64-byte records (format 4) unless the 80-byte ones are asked for; they address 2^26 nodes
+    bool compact = wide && ctx->opt_node_format != 3;
     rt_host::Bvh2 &bvh = ctx->hs->bvh;
     // (a tree built with leaves of more than 4 primitives cannot be collapsed into 8-ary nodes: rebuild)
     if (allow_refit && ctx->opt_refit != 0 && ctx->hs->bvh_prims == n_prims && n_prims > 0 && !(wide && bvh.max_leaf > 4)) {
@@ -621,14 +639,27 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     // 8-ary nodes (format 3) wherever they fit; else binary nodes: 32-byte q8 records when the scene's extent fits AND the
     // nodes are too many to stay in the caches (measured: C4, 244 MB of 48-byte nodes, 8 % faster; C3, 0.26 MB, 2 % slower)
     rp.wide = wide;
+    rp.compact = compact;
     rp.q8 = !wide && fits && ctx->opt_node_format == 2;
     if (rp.q8) rp.node_stride = 2;
     if (rp.wide) rp.node_stride = ctx->opt_node_stride == 8 ? 8u : (uint32_t)RT_NODE8_CHUNKS;
+    if (rp.compact) {
+        rp.node_stride = RT_NODE8C_CHUNKS;
+        rt_grid_for(scene_box.lo, scene_box.hi, rp.grid_lo, rp.grid_cell);
+    }
     repack(bvh, corners, ids, *ctx, rp, boxes.data());
+    if (rp.compact && rp.nodes8c.size() > RT_NODE8C_MAX_NODES) {
+        // more nodes than a 26-bit child index addresses (beyond ~300 M primitives): the 80-byte records instead
+        compact = false;
+        rp = Repacked();
+        rp.wide = true;
+        rp.node_stride = RT_NODE8_CHUNKS;
+        repack(bvh, corners, ids, *ctx, rp, boxes.data());
+    }
     out.build_seconds = bvh.build_seconds;
     out.n_prims = n_prims;
     convert_materials(*ctx, out.mats);
-    if (rp.wide && rp.node_stride != RT_NODE8_CHUNKS) {
+    if (rp.wide && !rp.compact && rp.node_stride != RT_NODE8_CHUNKS) {
         const size_t pitch = (size_t)rp.node_stride * 16u;
         out.packed_nodes.assign(rp.nodes8.size() * pitch, 0);
         for (size_t i = 0; i < rp.nodes8.size(); i++) memcpy(out.packed_nodes.data() + i * pitch, &rp.nodes8[i], sizeof(DevNode8));
@@ -655,17 +686,20 @@ int device_upload(rt_context *ctx, const Built &b) {
     ctx->models_committed = true;    // from here on the device scene is being replaced
     ctx->have_scene = false;
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
-    const size_t n_nodes = rp.wide ? rp.nodes8.size() : rp.nodes.size();
+    const size_t n_nodes = rp.compact ? rp.nodes8c.size() : (rp.wide ? rp.nodes8.size() : rp.nodes.size());
     const size_t node_bytes = n_nodes * (size_t)rp.node_stride * 16u;
     RT_HIP(hipMalloc((void **)&ctx->d_nodes, node_bytes));
     RT_HIP(hipMalloc((void **)&ctx->d_tris, rp.tris.size() * sizeof(DevTri)));
     RT_HIP(hipMalloc((void **)&ctx->d_shade, rp.shade.size() * sizeof(DevShade)));
     RT_HIP(hipMalloc((void **)&ctx->d_materials, mats.size() * sizeof(DevMaterial)));
     ctx->materials_capacity = mats.size();
-    const void *node_src = rp.wide ? (rp.node_stride == RT_NODE8_CHUNKS ? (const void *)rp.nodes8.data() : (const void *)b.packed_nodes.data())
+    const void *node_src = rp.compact ? (const void *)rp.nodes8c.data() : rp.wide ? (rp.node_stride == RT_NODE8_CHUNKS ? (const void *)rp.nodes8.data() : (const void *)b.packed_nodes.data())
                                    : (rp.node_stride == RT_NODE_CHUNKS ? (const void *)rp.nodes.data() : (const void *)b.packed_nodes.data());
     RT_HIP(hipMemcpy(ctx->d_nodes, node_src, node_bytes, hipMemcpyHostToDevice));
     ctx->node_wide = rp.wide;
+    ctx->node_compact = rp.compact;
+    memcpy(ctx->grid_lo, rp.grid_lo, sizeof ctx->grid_lo);
+    memcpy(ctx->grid_cell, rp.grid_cell, sizeof ctx->grid_cell);
     ctx->node_bytes = node_bytes;
     ctx->node_stride = rp.node_stride;
     ctx->node_q8 = rp.q8;
@@ -759,7 +793,12 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
         P.stage_stride = (uint64_t)P.local_rows * ctx->width;
     }
     P.node_q8 = ctx->node_q8 ? 1u : 0u;
-    P.node_wide = ctx->node_wide ? 1u : 0u;
+    P.node_wide = ctx->node_wide ? (ctx->node_compact ? 2u : 1u) : 0u;
+    for (int k = 0; k < 3; k++) {
+        P.grid_lo[k] = ctx->grid_lo[k];
+        const float c = ctx->grid_cell[k] * 0.00390625f;         // cell * 2^-8: the kernel adds the node's 4-bit exponent to its bit pattern
+        memcpy(&P.grid_cell_bits[k], &c, 4);
+    }
     P.nodes = ctx->d_nodes; P.tris = ctx->d_tris; P.shade = ctx->d_shade; P.materials = ctx->d_materials;
     P.textures = ctx->d_textures; P.texels = ctx->d_texels; P.n_textures = ctx->n_textures;
     P.n_materials = (uint32_t)ctx->materials_capacity;      // records actually uploaded (the LDS preload copies that many)
@@ -806,9 +845,9 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
         RT_HIP(hipMemsetAsync(P.queue, 0, sizeof(DevQueue), ctx->stream));     // the head must start at zero, whatever the last call left
         const bool ext = !ctx->hs->spheres.empty() || ctx->n_textures > 0;
         const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
-        const int sel = (ctx->node_wide ? 32 : 0) | (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
+        const int sel = (ctx->node_compact ? 64 : 0) | (ctx->node_wide ? 32 : 0) | (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
         if (ctx->persistent_blocks == 0 || ctx->persistent_sel != sel) {
-            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm, ctx->node_wide ? 2 : (ctx->node_q8 ? 1 : 0));
+            ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm, ctx->node_wide ? (ctx->node_compact ? 3 : 2) : (ctx->node_q8 ? 1 : 0));
             ctx->persistent_sel = sel;
             // Resident workgroups per CU.  More waves hide more latency only while their rays' working set stays in the caches and the
             // TLB; measured (8-ary nodes, ms per step at 3 / 4 / 5 workgroups): C4, 2 GB of records: 126 / 109 / 102; C5q, 10 GB:
@@ -889,9 +928,11 @@ int device_refit(rt_context *ctx) {
         xform = ctx->d_xform;
     }
     const float prim_pad = rt_prim_pad(ctx->prim_pad_scale);
+    const float grid6[6] = {ctx->grid_lo[0], ctx->grid_lo[1], ctx->grid_lo[2], ctx->grid_cell[0], ctx->grid_cell[1], ctx->grid_cell[2]};
     if (ctx->node_wide)
         RT_HIP(rt_launch_refit8(ctx->d_tris, ctx->d_shade, xform, ctx->d_tribox, ctx->n_tris, reinterpret_cast<float4 *>(ctx->d_nodes), ctx->node_stride,
-                                ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, prim_pad, ctx->stream));
+                                ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, prim_pad,
+                                ctx->node_compact ? grid6 : nullptr, ctx->stream));
     else
     RT_HIP(rt_launch_refit(ctx->d_tris, ctx->d_shade, xform, ctx->d_tribox, ctx->n_tris, reinterpret_cast<float4 *>(ctx->d_nodes), ctx->node_stride,
                            ctx->d_parent, ctx->d_arrived, ctx->d_cbox, (uint32_t)ctx->n_nodes, ctx->d_root, ctx->node_q8,
@@ -909,6 +950,8 @@ int device_refit(rt_context *ctx) {
         // the moved scene may have outgrown what 8-bit offsets can span (their outward rounding saturates there):
         // rebuild on the host, which chooses the node format again
         if (!rt_q8_fits(root.lo, root.hi)) return build_and_upload(ctx, true);
+        // compact 8-ary nodes: their corners are cells of the grid laid out at the last host build; a scene that moved out of it is rebuilt
+        if (ctx->node_compact && !rt_grid_holds(root.lo, root.hi, ctx->grid_lo, ctx->grid_cell)) return build_and_upload(ctx, true);
     }
     return RT_OK;
 }
@@ -938,7 +981,7 @@ int rt_create(int device_id, rt_context **out) {
     // developer default for RT_OPT_NODE_FORMAT (tests/test_gpu_wide_nodes.py runs the whole parity suite on the 8-ary format this way)
     if (const char *e = getenv("RT_AMD_NODE_FORMAT")) {
         const int v = atoi(e);
-        if (v >= 0 && v <= 3) ctx->opt_node_format = v;
+        if (v >= 0 && v <= 4) ctx->opt_node_format = v;
     }
     (void)hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device_id);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -995,7 +1038,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             return RT_OK;
         case RT_OPT_FRAME_PIPELINE: ctx->opt_pipeline = value != 0; return RT_OK;
         case RT_OPT_NODE_FORMAT:
-            if (value < 0 || value > 3) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_FORMAT: 0 (automatic), 1 (48-byte binary), 2 (32-byte binary) or 3 (80-byte 8-ary)");
+            if (value < 0 || value > 4) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_NODE_FORMAT: 0 (automatic), 1 (48-byte binary), 2 (32-byte binary), 3 (80-byte 8-ary) or 4 (64-byte 8-ary)");
             ctx->opt_node_format = (int)value;
             return RT_OK;
         case RT_OPT_NODE_STRIDE:

@@ -52,6 +52,23 @@ struct alignas(16) DevNode8 {
 static_assert(sizeof(DevNode8) == 80, "DevNode8");
 #define RT_NODE8_CHUNKS 5
 
+// The compact 8-ary node (RT_OPT_NODE_FORMAT = 4): the same tree and the same plane dwords in 64 bytes = FOUR fetches and ONE
+// 64-byte line per visit (the 80-byte record straddles two).  The node's lower corner is not three floats but three 14-bit
+// cell indices of a per-scene grid (RenderParams::grid_lo / grid_cell: a power-of-two cell, the scene's box plus a margin in
+// 2^14 cells), rounded down; the plane offsets count steps of cell * 2^(e - 8) with one 4-bit e per axis.  A coarse corner
+// costs next to nothing: the planes are relative to the corner as stored, so only their step grows by the fraction of a
+// cell the corner moved.  Header (128 bits):
+//   w0 = fx | fy << 14 | ex << 28          w1 = fz | ey << 14 | ez << 18 | imask << 22
+//   w2 = child_base (node INDEX, 26 bits) | (lmask & 63) << 26          w3 = tri_base (28 bits) | (lmask >> 6) << 28
+struct alignas(16) DevNode8c {
+    uint32_t w0, w1, w2, w3;
+    uint32_t qx[4], qy[4], qz[4];
+};
+static_assert(sizeof(DevNode8c) == 64, "DevNode8c");
+#define RT_NODE8C_CHUNKS 4
+#define RT_NODE8C_MAX_NODES (1u << 26)
+#define RT_GRID_BITS 14
+
 // Child reference: >= 0 → inner DevNode, as its index * RT_NODE_CHUNKS (a
 // float4 index: the address needs a shift only); < 0 → leaf, with
 // ~ref = (first_slot << 3) | count, count in 0..7 (0 = empty child).
@@ -137,7 +154,10 @@ struct RenderParams {
     const DevTexture *textures;   // EXT builds only
     const uint32_t *texels;
     uint32_t node_q8, node_wide;         // node_q8 = 1: 32-byte binary nodes with 8-bit plane offsets (rt_pack.h), stride 2 chunks;
-                                         // node_wide = 1: 80-byte 8-ary nodes (DevNode8), `nodes` points at them
+                                         // node_wide = 1: 80-byte 8-ary nodes (DevNode8), 2: 64-byte ones (DevNode8c); `nodes` points at them
+    float grid_lo[3];                    // DevNode8c: lower corner of the corner grid
+    uint32_t grid_cell_bits[3];          // DevNode8c: bit pattern of (grid cell * 2^-8), a power of two, per axis
+    uint32_t pad_grid[2];
     uint32_t n_textures, n_materials;   // n_materials: records behind `materials`
     float *accum;            // local rows x W x 4 f32
     uint32_t *aov;           // local rows x W x 2 u32, or null

@@ -285,15 +285,44 @@ __device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v 
 // One visit: all eight child boxes of the node at 16-byte chunk `chunk` against the ray (ix.. = stuffed inverses, ox.. =
 // -o * inv, eps: see make_slab).  Returns the hit mask over the node's present children.  Conservative like the binary
 // nodes' test: planes are rounded outward at build time, the far bound is widened by kFarSlack and eps.
-__device__ __forceinline__ uint32_t test_node8(const float4 *__restrict__ n, float ix, float iy, float iz, float ox, float oy, float oz,
+// COMPACT: the 64-byte record (DevNode8c): four fetches; the corner is three 14-bit cell indices of the scene's grid and ox.. are
+// expected in GRID space (grid_lo * inv - o * inv, see wide_origin), the plane step is cell * 2^(e - 8) per axis.
+template <bool COMPACT>
+__device__ __forceinline__ uint32_t test_node8(const RenderParams &P, const float4 *__restrict__ n, float ix, float iy, float iz, float ox, float oy, float oz,
                                                float eps, float tbest, uint32_t &child_base, uint32_t &tri_base, uint32_t &imask, uint32_t &lmask) {
-    const float4 a = ld4(n);
-    const uint4 b = ld4u(n + 1), qx = ld4u(n + 2), qy = ld4u(n + 3), qz = ld4u(n + 4);
-    const uint32_t w = __float_as_uint(a.w);
-    // per-axis scale 2^(byte - 127) times the inverse direction
-    const float sx = __uint_as_float((w & 0xffu) << 23) * ix, sy = __uint_as_float(((w >> 8) & 0xffu) << 23) * iy,
-                sz = __uint_as_float(((w >> 16) & 0xffu) << 23) * iz;
-    const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
+    float sx, sy, sz, bx, by, bz;
+    uint4 qx, qy, qz;
+    if (COMPACT) {
+        const uint4 hd = ld4u(n);
+        qx = ld4u(n + 1); qy = ld4u(n + 2); qz = ld4u(n + 3);
+        // step = cell * 2^(e - 8): the exponent is added to the bit pattern of (cell * 2^-8), a power of two
+        sx = __uint_as_float(P.grid_cell_bits[0] + ((hd.x >> 28) << 23)) * ix;
+        sy = __uint_as_float(P.grid_cell_bits[1] + (((hd.y >> 14) & 15u) << 23)) * iy;
+        sz = __uint_as_float(P.grid_cell_bits[2] + (((hd.y >> 18) & 15u) << 23)) * iz;
+        // corner = grid_lo + index * cell; cell = (cell * 2^-8) * 256
+        const float gx = __uint_as_float(P.grid_cell_bits[0] + (8u << 23)) * ix, gy = __uint_as_float(P.grid_cell_bits[1] + (8u << 23)) * iy,
+                    gz = __uint_as_float(P.grid_cell_bits[2] + (8u << 23)) * iz;
+        bx = fmaf((float)(hd.x & 0x3fffu), gx, ox);
+        by = fmaf((float)((hd.x >> 14) & 0x3fffu), gy, oy);
+        bz = fmaf((float)(hd.y & 0x3fffu), gz, oz);
+        imask = (hd.y >> 22) & 0xffu;
+        lmask = (hd.z >> 26) | (((hd.w >> 28) << 6) & 0xc0u);
+        child_base = (hd.z & 0x3ffffffu) << 2;              // node index -> 16-byte chunk index
+        tri_base = hd.w & 0xfffffffu;
+    } else {
+        const float4 a = ld4(n);
+        const uint4 b = ld4u(n + 1);
+        qx = ld4u(n + 2); qy = ld4u(n + 3); qz = ld4u(n + 4);
+        const uint32_t w = __float_as_uint(a.w);
+        // per-axis scale 2^(byte - 127) times the inverse direction
+        sx = __uint_as_float((w & 0xffu) << 23) * ix; sy = __uint_as_float(((w >> 8) & 0xffu) << 23) * iy;
+        sz = __uint_as_float(((w >> 16) & 0xffu) << 23) * iz;
+        bx = fmaf(a.x, ix, ox); by = fmaf(a.y, iy, oy); bz = fmaf(a.z, iz, oz);
+        imask = w >> 24;
+        lmask = b.z & 0xffu;
+        child_base = b.x;
+        tri_base = b.y;
+    }
     const uint32_t rx = __float_as_uint(ix), ry = __float_as_uint(iy), rz = __float_as_uint(iz);
     const uint32_t QX[4] = {qx.x, qx.y, qx.z, qx.w}, QY[4] = {qy.x, qy.y, qy.z, qy.w}, QZ[4] = {qz.x, qz.y, qz.z, qz.w};
     uint32_t h = 0;
@@ -312,12 +341,11 @@ __device__ __forceinline__ uint32_t test_node8(const float4 *__restrict__ n, flo
             asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(tn), "v"(lim) : "vcc");
         }
     }
-    imask = w >> 24;
-    lmask = b.z & 0xffu;
-    child_base = b.x;
-    tri_base = b.y;
     return h & (imask | lmask);
 }
+
+// -o * inv, or for the compact record the same in the corner grid's space: grid_lo * inv - o * inv
+__device__ __forceinline__ float wide_origin(bool compact, float grid_lo, float o, float inv) { return compact ? fmaf(grid_lo, inv, -(o * inv)) : -(o * inv); }
 
 // nearest committed hit through the 8-ary tree, one whole ray per call (kernel variants 0 and 1)
 template <bool COUNT, bool SPH>
@@ -326,10 +354,12 @@ __device__ __forceinline__ Hit trace8(const RenderParams &P, uint32_t *__restric
     best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
     const bool cull = (P.flags & 1u) != 0;
     const bool cw = P.front_face_cw != 0;
+    const bool compact = P.node_wide == 2u;
+    const uint32_t stride = compact ? (uint32_t)RT_NODE8C_CHUNKS : P.wide_stride;
     const float ix = stuffed_inverse(d.x), iy = stuffed_inverse(d.y), iz = stuffed_inverse(d.z);
-    const float ox = -(o.x * ix), oy = -(o.y * iy), oz = -(o.z * iz);
-    const float eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(ox)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(oy))),
-                                             fmaf(P.scene_abs[2], fabsf(iz), fabsf(oz)));
+    const float eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(o.x * ix)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(o.y * iy))),
+                                             fmaf(P.scene_abs[2], fabsf(iz), fabsf(o.z * iz)));
+    const float ox = wide_origin(compact, P.grid_lo[0], o.x, ix), oy = wide_origin(compact, P.grid_lo[1], o.y, iy), oz = wide_origin(compact, P.grid_lo[2], o.z, iz);
     const uint32_t flip256 = ((__float_as_uint(ix) >> 31) | ((__float_as_uint(iy) >> 31) << 1) | ((__float_as_uint(iz) >> 31) << 2)) << 8;
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(P.nodes);
     uint32_t ng_base = 0, ng_mask = 0x0101u, tg_base = 0, tg_mask = 0;   // the root: the only child of a virtual group
@@ -354,15 +384,16 @@ __device__ __forceinline__ Hit trace8(const RenderParams &P, uint32_t *__restric
         }
         const uint32_t slot = g_lds_next_slot[flip256 | (ng_mask & 0xffu)];
         ng_mask &= ~(1u << slot);
-        const uint32_t node = ng_base + P.wide_stride * (uint32_t)__popc((ng_mask >> 8) & ((1u << slot) - 1u));
+        const uint32_t node = ng_base + stride * (uint32_t)__popc((ng_mask >> 8) & ((1u << slot) - 1u));
         if (ng_mask & 0xffu) {
             if (kGuard && (uint32_t)(sp + 2) > P.stack_entries) { tl.guard++; }
             else { stack[sp * kBlock] = ng_base; stack[(sp + 1) * kBlock] = ng_mask; sp += 2; }
         }
-        if (kGuard && node + 5u > P.n_node_chunks) { tl.guard++; return best; }
+        if (kGuard && node + stride > P.n_node_chunks) { tl.guard++; return best; }
         if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
         uint32_t imask, lmask;
-        const uint32_t h = test_node8(nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
+        const uint32_t h = compact ? test_node8<true>(P, nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask)
+                                   : test_node8<false>(P, nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
         ng_mask = (h & imask) | (imask << 8);
         tg_mask = (h & lmask) | (lmask << 8);
     }
@@ -727,10 +758,10 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_FETCH = 4, PH_DONE = 5 };
 constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel-frame that has not started its first path
 
-// FMT: node format — 0 = 48-byte binary nodes, 1 = 32-byte binary nodes (q8), 2 = 80-byte 8-ary nodes (DevNode8)
+// FMT: node format — 0 = 48-byte binary nodes, 1 = 32-byte binary nodes (q8), 2 = 80-byte 8-ary nodes (DevNode8), 3 = 64-byte 8-ary nodes (DevNode8c)
 template <bool COUNT, bool AOV, bool SPH, bool LDSM, int FMT>
-__global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
-    constexpr bool Q8 = FMT == 1, WIDE = FMT == 2;
+__global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
+    constexpr bool Q8 = FMT == 1, WIDE = FMT >= 2, COMPACT = FMT == 3;
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
     if (WIDE) fill_next_slot_table();
@@ -772,6 +803,7 @@ __global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
         ox = -(S.pos.x * ix); oy = -(S.pos.y * iy); oz = -(S.pos.z * iz);
         eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(ox)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(oy))),
                                      fmaf(P.scene_abs[2], fabsf(iz), fabsf(oz)));   // see make_slab
+        if (COMPACT) { ox = fmaf(P.grid_lo[0], ix, ox); oy = fmaf(P.grid_lo[1], iy, oy); oz = fmaf(P.grid_lo[2], iz, oz); }   // into the corner grid's space
         best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
         cur = 0; sptr = stack;
         if (WIDE) {
@@ -827,8 +859,8 @@ __global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                     if (phase == PH_NODE) {
                         const uint32_t slot = g_lds_next_slot[flip256 | (ng_mask & 0xffu)];
                         ng_mask &= ~(1u << slot);
-                        const uint32_t node = ng_base + P.wide_stride * (uint32_t)__popc((ng_mask >> 8) & ((1u << slot) - 1u));
-                        if (kGuard && (node + 5u > P.n_node_chunks || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
+                        const uint32_t node = ng_base + (COMPACT ? (uint32_t)RT_NODE8C_CHUNKS : P.wide_stride) * (uint32_t)__popc((ng_mask >> 8) & ((1u << slot) - 1u));
+                        if (kGuard && (node + (COMPACT ? 4u : 5u) > P.n_node_chunks || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
                         else {
                             if (ng_mask & 0xffu) {               // siblings still to visit: the group goes on the stack
                                 if (kGuard && sptr + kBlock >= stack_end) { tl.guard++; }
@@ -848,7 +880,7 @@ __global__ __launch_bounds__(kBlock, FMT == 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                             }
 #endif
                             uint32_t imask, lmask;
-                            const uint32_t h = test_node8(nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
+                            const uint32_t h = test_node8<COMPACT>(P, nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
                             ng_mask = (h & imask) | (imask << 8);
                             tg_mask = (h & lmask) | (lmask << 8);
                             wide_advance();
@@ -1129,7 +1161,7 @@ static const void *phased_instance(int sel) {
     }
 }
 
-// fmt: 0 = 48-byte binary nodes, 1 = 32-byte binary nodes, 2 = 8-ary nodes
+// fmt: 0 = 48-byte binary nodes, 1 = 32-byte binary nodes, 2 = 80-byte 8-ary nodes, 3 = 64-byte 8-ary nodes
 int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, int fmt) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
@@ -1138,8 +1170,8 @@ int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool ao
     // the instances differ in register count (and static LDS), hence in how many workgroups fit
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
     const void *fn;
-    if (lds_materials) fn = fmt == 2 ? phased_instance<true, 2>(sel) : (fmt == 1 ? phased_instance<true, 1>(sel) : phased_instance<true, 0>(sel));
-    else fn = fmt == 2 ? phased_instance<false, 2>(sel) : (fmt == 1 ? phased_instance<false, 1>(sel) : phased_instance<false, 0>(sel));
+    if (lds_materials) fn = fmt == 3 ? phased_instance<true, 3>(sel) : (fmt == 2 ? phased_instance<true, 2>(sel) : (fmt == 1 ? phased_instance<true, 1>(sel) : phased_instance<true, 0>(sel)));
+    else fn = fmt == 3 ? phased_instance<false, 3>(sel) : (fmt == 2 ? phased_instance<false, 2>(sel) : (fmt == 1 ? phased_instance<false, 1>(sel) : phased_instance<false, 0>(sel)));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu * prop.multiProcessorCount;
 }
@@ -1151,12 +1183,14 @@ static hipError_t launch_variant(const RenderParams &P, int variant, dim3 tile_g
     if (variant == 0) return launch(rt_render_persistent<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
     // LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS); Q8: 32-byte nodes
     const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
-    const int fmt = P.node_wide ? 2 : (P.node_q8 ? 1 : 0);
+    const int fmt = P.node_wide ? (int)P.node_wide + 1 : (P.node_q8 ? 1 : 0);
     if (ldsm) {
+        if (fmt == 3) return launch(rt_render_phased<COUNT, AOV, SPH, true, 3>, persistent_grid, lds, stream, P);
         if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, true, 2>, persistent_grid, lds, stream, P);
         if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, true, 1>, persistent_grid, lds, stream, P);
         return launch(rt_render_phased<COUNT, AOV, SPH, true, 0>, persistent_grid, lds, stream, P);
     }
+    if (fmt == 3) return launch(rt_render_phased<COUNT, AOV, SPH, false, 3>, persistent_grid, lds, stream, P);
     if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, false, 2>, persistent_grid, lds, stream, P);
     if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, false, 1>, persistent_grid, lds, stream, P);
     return launch(rt_render_phased<COUNT, AOV, SPH, false, 0>, persistent_grid, lds, stream, P);

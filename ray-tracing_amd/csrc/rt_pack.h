@@ -173,6 +173,85 @@ RT_HD void rt_pack_node8(DevNode8 &n, const float (*blo)[3], const float (*bhi)[
     for (int p = 0; p < 4; p++) { n.qx[p] = q[0][p]; n.qy[p] = q[1][p]; n.qz[p] = q[2][p]; }
 }
 
+// ---- compact 8-ary node (DevNode8c) ----
+RT_HD uint32_t rt_node8c_imask(const DevNode8c &n) { return (n.w1 >> 22) & 0xffu; }
+RT_HD uint32_t rt_node8c_lmask(const DevNode8c &n) { return (n.w2 >> 26) | ((n.w3 >> 28) << 6 & 0xc0u); }
+RT_HD uint32_t rt_node8c_child_base(const DevNode8c &n) { return n.w2 & 0x3ffffffu; }
+RT_HD uint32_t rt_node8c_tri_base(const DevNode8c &n) { return n.w3 & 0xfffffffu; }
+RT_HD void rt_node8c_set_links(DevNode8c &n, uint32_t imask, uint32_t lmask, uint32_t child_base, uint32_t tri_base) {
+    n.w1 = (n.w1 & 0x003fffffu) | ((imask & 0xffu) << 22);
+    n.w2 = (child_base & 0x3ffffffu) | ((lmask & 0x3fu) << 26);
+    n.w3 = (tri_base & 0xfffffffu) | (((lmask >> 6) & 3u) << 28);
+}
+// The corner grid of a scene: power-of-two cells, 2^RT_GRID_BITS of them per axis covering the (padded) scene box plus a quarter
+// of its extent on either side, so that a refit may move things a little without leaving the grid.
+RT_HD void rt_grid_for(const float *scene_lo, const float *scene_hi, float *grid_lo, float *grid_cell) {
+    for (int k = 0; k < 3; k++) {
+        const double ext = (double)scene_hi[k] - (double)scene_lo[k];
+        const double want = (ext > 0.0 ? ext * 1.5 : 1.0) / (double)(1u << RT_GRID_BITS);
+        int e;
+        frexp(want, &e);                                     // want = m * 2^e, m in [0.5, 1): 2^e >= want
+        if (e < -100) e = -100;
+        grid_cell[k] = (float)ldexp(1.0, e);
+        // lower corner: a multiple of the cell at or below (scene_lo - ext / 4), so that cell arithmetic in doubles is exact
+        grid_lo[k] = (float)(floor(((double)scene_lo[k] - 0.25 * ext) / (double)grid_cell[k]) * (double)grid_cell[k]);
+    }
+}
+// true when [lo, hi] lies inside the grid (with room for the padding the packer adds)
+RT_HD bool rt_grid_holds(const float *lo, const float *hi, const float *grid_lo, const float *grid_cell) {
+    for (int k = 0; k < 3; k++) {
+        const double top = (double)grid_lo[k] + (double)grid_cell[k] * (double)((1u << RT_GRID_BITS) - 2u);
+        if (!((double)rt_pad_lo(lo[k]) >= (double)grid_lo[k] && (double)rt_pad_hi(hi[k]) <= top)) return false;
+    }
+    return true;
+}
+// One compact node: child boxes -> corner cell indices, per-axis step exponents, outward-rounded plane offsets.  Links are left alone.
+RT_HD void rt_pack_node8c(DevNode8c &n, const float (*blo)[3], const float (*bhi)[3], uint32_t present_mask, const float *grid_lo, const float *grid_cell) {
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
+    for (int c = 0; c < 8; c++) {
+        if (!((present_mask >> c) & 1u)) continue;
+        for (int k = 0; k < 3; k++) {
+            const double l = rt_pad_lo(blo[c][k]), h = rt_pad_hi(bhi[c][k]);
+            if (!any || l < lo[k]) lo[k] = l;
+            if (!any || h > hi[k]) hi[k] = h;
+        }
+        any = true;
+    }
+    uint32_t f[3], e4[3];
+    double corner[3], inv_step[3];
+    for (int k = 0; k < 3; k++) {
+        double cell = floor((lo[k] - (double)grid_lo[k]) / (double)grid_cell[k]);
+        const double top = (double)((1u << RT_GRID_BITS) - 1u);
+        if (!(cell >= 0.0)) cell = 0.0;                      // (outside the grid: the caller checks rt_grid_holds; stay defined)
+        if (cell > top) cell = top;
+        f[k] = (uint32_t)cell;
+        corner[k] = (double)grid_lo[k] + cell * (double)grid_cell[k];
+        const double ext = any ? hi[k] - corner[k] : 0.0;
+        int e = 0;                                           // step = cell * 2^(e - 8)
+        while (e < 15 && 255.0 * ldexp((double)grid_cell[k], e - 8) < ext) e++;
+        e4[k] = (uint32_t)e;
+        inv_step[k] = 1.0 / ldexp((double)grid_cell[k], e - 8);
+    }
+    uint32_t q[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int c = 0; c < 8; c++) {
+        const bool present = (present_mask >> c) & 1u;
+        for (int k = 0; k < 3; k++) {
+            uint32_t ql = 255u, qh = 0u;                       // absent: an inverted box
+            if (present) {
+                const double l = floor(((double)rt_pad_lo(blo[c][k]) - corner[k]) * inv_step[k]);
+                const double h = ceil(((double)rt_pad_hi(bhi[c][k]) - corner[k]) * inv_step[k]);
+                ql = l >= 0.0 && l <= 255.0 ? (uint32_t)l : (l < 0.0 ? 0u : 255u);
+                qh = h >= 0.0 && h <= 255.0 ? (uint32_t)h : (h > 255.0 ? 255u : 0u);
+            }
+            q[k][c >> 1] |= (ql << (8 * (c & 1))) | (qh << (16 + 8 * (c & 1)));
+        }
+    }
+    n.w0 = f[0] | (f[1] << 14) | (e4[0] << 28);
+    n.w1 = (n.w1 & 0xffc00000u) | f[2] | (e4[1] << 14) | (e4[2] << 18);
+    for (int p = 0; p < 4; p++) { n.qx[p] = q[0][p]; n.qy[p] = q[1][p]; n.qz[p] = q[2][p]; }
+}
+
 // geometry transform of one corner, the host's expression (host/bvh_builder.cpp gather_triangles): every
 // product and sum rounds once (this file is compiled with -ffp-contract=off on both sides)
 RT_HD void rt_transform_point(const float *m, const float *v, float *dst) {

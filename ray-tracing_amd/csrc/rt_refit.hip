@@ -98,19 +98,25 @@ __global__ __launch_bounds__(256) void rt_refit_nodes(float4 *__restrict__ chunk
 // The same walk for the 8-ary tree (DevNode8).  One thread per node; a thread whose node has no inner children packs it from its
 // primitives' boxes and carries the union to the parent; at a parent the LAST of its inner children to arrive (atomic counter
 // against popcount(imask)) packs it — leaf children's boxes from the primitives again, inner children's from cbox — and goes on up.
+struct RtGrid6 { float lo[3], cell[3]; };
+// COMPACT: 64-byte records (DevNode8c) whose corners are cells of the grid `G`
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void rt_refit_nodes8(float4 *__restrict__ chunks, uint32_t stride, const int32_t *__restrict__ parent,
                                                        unsigned int *__restrict__ arrived, RtRefitBox *cbox, const RtRefitBox *__restrict__ tribox,
-                                                       uint32_t n_nodes, uint64_t n_slots, RtRefitBox *root_out) {
+                                                       uint32_t n_nodes, uint64_t n_slots, RtRefitBox *root_out, RtGrid6 G) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_nodes) return;
-    {
-        const DevNode8 *nd = reinterpret_cast<const DevNode8 *>(chunks + (size_t)i * stride);
-        if ((nd->exps_imask >> 24) != 0u) return;             // has inner children: finished by the last of them
-    }
+    auto imask_of = [&](uint32_t node) -> uint32_t {
+        if (COMPACT) return rt_node8c_imask(*reinterpret_cast<const DevNode8c *>(chunks + (size_t)node * stride));
+        return reinterpret_cast<const DevNode8 *>(chunks + (size_t)node * stride)->exps_imask >> 24;
+    };
+    if (imask_of(i) != 0u) return;                            // has inner children: finished by the last of them
     uint32_t cur = i;
     for (;;) {
         DevNode8 *nd = reinterpret_cast<DevNode8 *>(chunks + (size_t)cur * stride);
-        const uint32_t imask = nd->exps_imask >> 24, lmask = nd->lmask & 0xffu;
+        DevNode8c *nc = reinterpret_cast<DevNode8c *>(chunks + (size_t)cur * stride);
+        const uint32_t imask = imask_of(cur), lmask = COMPACT ? rt_node8c_lmask(*nc) : (nd->lmask & 0xffu);
+        const uint64_t tri_base = COMPACT ? rt_node8c_tri_base(*nc) : nd->tri_base;
         float blo[8][3], bhi[8][3];
         RtRefitBox u;
         for (int k = 0; k < 3; k++) { u.lo[k] = INFINITY; u.hi[k] = -INFINITY; }
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256) void rt_refit_nodes8(float4 *__restrict__ chun
         for (uint32_t sl = 0; sl < 8u; sl++) {
             RtRefitBox b;
             if ((lmask >> sl) & 1u) {
-                const uint64_t slot = (uint64_t)nd->tri_base + leaf_rank++;
+                const uint64_t slot = tri_base + leaf_rank++;
                 if (slot < n_slots) b = tribox[slot];
                 else { for (int k = 0; k < 3; k++) { b.lo[k] = INFINITY; b.hi[k] = -INFINITY; } }
             } else if ((imask >> sl) & 1u) {
@@ -127,13 +133,13 @@ __global__ __launch_bounds__(256) void rt_refit_nodes8(float4 *__restrict__ chun
             for (int k = 0; k < 3; k++) { blo[sl][k] = b.lo[k]; bhi[sl][k] = b.hi[k]; }
             grow(u, b);
         }
-        rt_pack_node8(*nd, blo, bhi, imask | lmask);
+        if (COMPACT) rt_pack_node8c(*nc, blo, bhi, imask | lmask, G.lo, G.cell);
+        else rt_pack_node8(*nd, blo, bhi, imask | lmask);
         const int32_t p = parent[cur];
         if (p < 0) { *root_out = u; return; }
         cbox[(size_t)p] = u;                                        // p = parent node * 8 + child slot
         const uint32_t pn = (uint32_t)p >> 3;
-        const DevNode8 *pd = reinterpret_cast<const DevNode8 *>(chunks + (size_t)pn * stride);
-        const uint32_t expected = (uint32_t)__popc(pd->exps_imask >> 24);
+        const uint32_t expected = (uint32_t)__popc(imask_of(pn));
         __threadfence();                                            // my box is visible before I count as arrived
         if (atomicAdd(&arrived[pn], 1u) + 1u != expected) return;   // a sibling still to come finishes the parent
         __threadfence();                                            // and the siblings' boxes are visible to me
@@ -145,12 +151,18 @@ __global__ __launch_bounds__(256) void rt_refit_nodes8(float4 *__restrict__ chun
 
 hipError_t rt_launch_refit8(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
                             uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
-                            RtRefitBox *root_out, float prim_pad, hipStream_t stream) {
+                            RtRefitBox *root_out, float prim_pad, const float *grid_lo_cell, hipStream_t stream) {
     if (n_slots == 0 || n_nodes == 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(arrived, 0, (size_t)n_nodes * sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     rt_refit_tris<<<dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, stream>>>(tris, shade, xform, tribox, n_slots, prim_pad);
-    rt_refit_nodes8<<<dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream>>>(chunks, stride, parent, arrived, cbox, tribox, n_nodes, n_slots, root_out);
+    RtGrid6 G = {{0, 0, 0}, {1, 1, 1}};
+    if (grid_lo_cell) {
+        for (int k = 0; k < 3; k++) { G.lo[k] = grid_lo_cell[k]; G.cell[k] = grid_lo_cell[3 + k]; }
+        rt_refit_nodes8<true><<<dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream>>>(chunks, stride, parent, arrived, cbox, tribox, n_nodes, n_slots, root_out, G);
+    } else {
+        rt_refit_nodes8<false><<<dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream>>>(chunks, stride, parent, arrived, cbox, tribox, n_nodes, n_slots, root_out, G);
+    }
     return hipGetLastError();
 }
 

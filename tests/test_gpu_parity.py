@@ -635,7 +635,7 @@ def test_uniform_fields_are_honoured(rt, oracle_mod, oracle_scenes, ctxs, kw):
     assert np.array_equal(rgb.reshape(-1, 3), oracle_mod.capture_rgb8(want)) and np.array_equal(rgb.reshape(-1, 3), rt.capture_rgb8(got))
 
 
-@pytest.mark.parametrize("node_format", [1, 2, 3])
+@pytest.mark.parametrize("node_format", [1, 2, 3, 4])
 def test_models_update_device_refit(rt, oracle_mod, obj_loader, scenes, node_format):
     """RT_OPT_REFIT = 2: rt_models_update recomputes the triangle records and the node boxes ON the device
     (csrc/rt_refit.hip).  Same hit ids and image as the oracle for the moved geometry and as the host refit,

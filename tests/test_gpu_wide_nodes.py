@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.skipif(os.environ.get("RT_AMD_NODE_FORMAT") is not None, reason="already the child run")
-def test_parity_suite_on_8ary_nodes():
-    env = dict(os.environ, RT_AMD_NODE_FORMAT="3")
+@pytest.mark.parametrize("fmt", ["3", "4"])       # 80-byte and 64-byte 8-ary records
+def test_parity_suite_on_8ary_nodes(fmt):
+    env = dict(os.environ, RT_AMD_NODE_FORMAT=fmt)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider",
                         "tests/test_gpu_parity.py", "tests/test_textures.py", "tests/test_gpu_group.py", "tests/test_zz_no_alloc.py"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -32,13 +33,13 @@ def test_8ary_format_is_really_used(rt, scenes):
     from conftest import config
     s = scenes("teapot-circle")
     sizes = {}
-    for fmt in (1, 3):
+    for fmt in (1, 3, 4):
         with rt.Context(0) as ctx:
             ctx.set_option(rt.RT_OPT_NODE_FORMAT, fmt)
             ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
             st = ctx.stats()
             n_prims = len(s.indices) // 3
             sizes[fmt] = (st.bvh_nodes, (st.bvh_bytes - n_prims * (48 + 128)) / st.bvh_nodes, st.stack_entries)
-    assert sizes[1][1] == 48 and sizes[3][1] == 80
-    assert sizes[3][0] < sizes[1][0] / 1.8
-    assert sizes[3][2] <= 24
+    assert sizes[1][1] == 48 and sizes[3][1] == 80 and sizes[4][1] == 64
+    assert sizes[3][0] < sizes[1][0] / 1.8 and sizes[4][0] == sizes[3][0]
+    assert sizes[3][2] <= 24 and sizes[4][2] == sizes[3][2]

@@ -43,9 +43,9 @@ def run(name, scene, spheres, cam, w, h, samples, bounces, options=()):
 c1 = graft.load_config("C1")
 cornell = obj_loader.load(os.path.join(ROOT, c1["scene"]))
 # the window of the round-1 fault report (61x37), on every node format the kernel has
-for fmt in (1, 2, 3):
+for fmt in (1, 2, 3, 4):
     run(f"c1_61x37_format{fmt}", cornell, None, c1, 61, 37, 2, c1["max_bounces"], [(rt.RT_OPT_NODE_FORMAT, fmt)])
 lat = synth.lattice_scene(os.path.join(ROOT, "scenes", "teapot.obj"), 26, 300, seed=1)
 lscene = obj_loader.Scene(lat.vertices, lat.indices, lat.primitives, lat.models)
-for fmt in (1, 2, 3):
+for fmt in (1, 2, 3, 4):
     run(f"c4_lattice_26_format{fmt}", lscene, lat.spheres, lat.camera, 96, 54, 4, 8, [(rt.RT_OPT_NODE_FORMAT, fmt)])
