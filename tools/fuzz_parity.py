@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-tris", type=int, default=400, help="per geometry")
-ap.add_argument("--node-format", type=int, default=0, help="RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte, 2 32-byte nodes")
+ap.add_argument("--node-format", type=int, default=0, help="RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte, 2 32-byte binary nodes, 3 80-byte, 4 64-byte 8-ary nodes")
 args = ap.parse_args()
 rt = graft.load_package()
 rng = np.random.default_rng(args.seed)
