@@ -580,7 +580,7 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     // Every primitive's box is widened by 2^-17 of the scene's scale (rt_pack.h rt_prim_pad): the triangle test's
     // own rounding grows with the distance between ray origin and triangle and with 1 / |cos| of the incidence, so a ray that
     // grazes a triangle within rounding of its edge can be ACCEPTED by the test while passing beside the triangle's exact box.
-    // Found by tools/format_diff.py (one pixel-frame of config C4 at 1080p: the binary formats missed a hit that brute force,
+    // Found by tests/checkers/format_diff.py (one pixel-frame of config C4 at 1080p: the binary formats missed a hit that brute force,
     // the oracle's BVH and the 8-ary format find).  No finite pad is a proof (1 / |cos| is unbounded); this one makes the
     // case rarer by orders of magnitude for a fraction of a percent of extra box hits.
     {

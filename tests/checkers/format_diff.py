@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Render one frame of a config with two node formats, list the pixels whose bits differ and ask the oracle's BRUTE-FORCE
 mode (every primitive tested, no BVH: the ground truth of SURVEY section 8 A4) which one is right.
-usage: python tools/format_diff.py [config] [WxH] [fmtA] [fmtB] [max pixels to check] [frames: each frame number 1..N is rendered on its own]"""
+usage: python tests/checkers/format_diff.py [config] [WxH] [fmtA] [fmtB] [max pixels to check] [frames: each frame number 1..N is rendered on its own]"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import __graft_entry__ as graft

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Randomised parity run: random triangle soups (sizes, extents, offsets from the origin), random geometry
 transforms applied through rt_models_update (device refit), random cameras and materials; HIP path against the
-oracle's BRUTE-FORCE mode, bit for bit.  usage: python tools/fuzz_parity.py [--iters 40] [--seed 1]"""
+oracle's BRUTE-FORCE mode, bit for bit.  usage: python tests/checkers/fuzz_parity.py [--iters 40] [--seed 1]"""
 import argparse, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft
 from oracle import obj_loader, oracle

@@ -7,7 +7,7 @@ import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["RT_AMD_LIB"] = os.path.join(ROOT, "ray-tracing_amd", "librt_amd_guard.so")
 import numpy as np  # noqa: E402

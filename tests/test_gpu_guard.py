@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_guarded_build_never_trips():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard_check.py")], capture_output=True, text=True, timeout=280, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checkers", "guard_check.py")], capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     cases = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(cases) >= 4
