@@ -154,7 +154,7 @@ struct rt_context {
     // the 8-ary format is traversed by every kernel variant
     bool opt_kernel_wide_ok() const { return true; }
     int opt_kernel = 2;
-    int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE, workgroups per CU (0 = all that fit), FETCH weight, -, builder max_leaf, bins
+    int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE, workgroups per CU (0 = all that fit), FETCH weight, children per 8-ary node (4..8, else 8), builder max_leaf, bins
     float4 *d_stage = nullptr;       // per-frame sample sums of a multi-frame launch (lazy, grows)
     uint64_t stage_elems = 0;
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
@@ -195,6 +195,7 @@ struct Repacked {
     bool compact = false;            // wide: 64-byte records (DevNode8c) in `nodes8c`, node_stride 4
     std::vector<DevNode8c> nodes8c;
     float grid_lo[3] = {0.0f, 0.0f, 0.0f}, grid_cell[3] = {1.0f, 1.0f, 1.0f};   // compact: the corner grid (rt_pack.h rt_grid_for)
+    int width8 = 8;                  // wide: children a node may hold (developer knob 105: what a narrower tree would visit)
     std::vector<uint32_t> order8;    // wide: slot -> primitive id (a node's leaf children are consecutive slots)
     std::vector<int32_t> parent;     // node -> parent * 2 + child slot (device refit)
     bool refit_sources_agree = true; // shading-record corners == BLAS corners (see repack)
@@ -259,7 +260,7 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
             for (int i = 0; i < n_open; i++) {
                 const rt_host::Bvh2Node &c = bvh.nodes[open[i]];
                 if (c.count) continue;
-                if (total - 1 + size_of(c.left) + size_of(c.left + 1) > 8) continue;
+                if (total - 1 + size_of(c.left) + size_of(c.left + 1) > out.width8) continue;
                 const float a = half_area(c.box);
                 if (a > best) { best = a; pick = i; }
             }
@@ -640,6 +641,7 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     // nodes are too many to stay in the caches (measured: C4, 244 MB of 48-byte nodes, 8 % faster; C3, 0.26 MB, 2 % slower)
     rp.wide = wide;
     rp.compact = compact;
+    rp.width8 = (ctx->tune[5] >= 4 && ctx->tune[5] <= 8) ? ctx->tune[5] : 8;
     rp.q8 = !wide && fits && ctx->opt_node_format == 2;
     if (rp.q8) rp.node_stride = 2;
     if (rp.wide) rp.node_stride = ctx->opt_node_stride == 8 ? 8u : (uint32_t)RT_NODE8_CHUNKS;
