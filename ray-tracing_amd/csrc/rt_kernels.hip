@@ -31,6 +31,18 @@
 #include "rt_math.h"
 #include "rt_pack.h"
 
+// This file is compiled TWICE (Makefile): -DRT_TU_PHASED = variant 2 and the blend kernel, built with
+// -mllvm -structurizecfg-skip-uniform-regions; -DRT_TU_SIMPLE = variants 0 and 1 and the launcher, built WITHOUT that flag.
+// The flag keeps wave-uniform branches out of the structurizer (4 % on C3), and it MISCOMPILES a uniform branch whose arms
+// hold divergent loops: step() below, the whole-ray traversals of variants 0 / 1 chosen by node format, lost hits in
+// rt_render_persistent<false, false, true> on 8-ary nodes (found by tests/checkers/fuzz_parity.py).
+// The phased kernel has no divergent loop at all — every loop in it exits on a wave-uniform condition — and is the only
+// code that gets the flag.  With neither macro (tools/kernel_regs.sh, tools/isa_bodies.py) the file is one unit.
+#if !defined(RT_TU_PHASED) && !defined(RT_TU_SIMPLE)
+#define RT_TU_PHASED 1
+#define RT_TU_SIMPLE 1
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;                  // 4 waves per workgroup
@@ -348,13 +360,13 @@ __device__ __forceinline__ uint32_t test_node8(const RenderParams &P, const floa
 __device__ __forceinline__ float wide_origin(bool compact, float grid_lo, float o, float inv) { return compact ? fmaf(grid_lo, inv, -(o * inv)) : -(o * inv); }
 
 // nearest committed hit through the 8-ary tree, one whole ray per call (kernel variants 0 and 1)
-template <bool COUNT, bool SPH>
+template <bool COUNT, bool SPH, bool COMPACT>
 __device__ __forceinline__ Hit trace8(const RenderParams &P, uint32_t *__restrict__ stack, rt_v3 o, rt_v3 d, Tally &tl) {
     Hit best;
     best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
     const bool cull = (P.flags & 1u) != 0;
     const bool cw = P.front_face_cw != 0;
-    const bool compact = P.node_wide == 2u;
+    constexpr bool compact = COMPACT;
     const uint32_t stride = compact ? (uint32_t)RT_NODE8C_CHUNKS : P.wide_stride;
     const float ix = stuffed_inverse(d.x), iy = stuffed_inverse(d.y), iz = stuffed_inverse(d.z);
     const float eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(o.x * ix)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(o.y * iy))),
@@ -392,8 +404,7 @@ __device__ __forceinline__ Hit trace8(const RenderParams &P, uint32_t *__restric
         if (kGuard && node + stride > P.n_node_chunks) { tl.guard++; return best; }
         if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
         uint32_t imask, lmask;
-        const uint32_t h = compact ? test_node8<true>(P, nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask)
-                                   : test_node8<false>(P, nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
+        const uint32_t h = test_node8<COMPACT>(P, nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
         ng_mask = (h & imask) | (imask << 8);
         tg_mask = (h & lmask) | (lmask << 8);
     }
@@ -639,7 +650,8 @@ __device__ __forceinline__ bool shade(const RenderParams &P, const Camera &C, Pi
 
 template <bool COUNT, bool AOV, bool SPH>
 __device__ __forceinline__ bool step(const RenderParams &P, const Camera &C, uint32_t *stack, PixelState &S, Tally &tl) {
-    Hit h = P.node_wide ? trace8<COUNT, SPH>(P, stack, S.pos, S.dir, tl) : trace<COUNT, SPH>(P, stack, S.pos, S.dir, tl);   // main.wgsl:44
+    Hit h = P.node_wide == 2u ? trace8<COUNT, SPH, true>(P, stack, S.pos, S.dir, tl)
+          : P.node_wide     ? trace8<COUNT, SPH, false>(P, stack, S.pos, S.dir, tl) : trace<COUNT, SPH>(P, stack, S.pos, S.dir, tl);   // main.wgsl:44
     tl.rays++;
     return shade<AOV, SPH>(P, C, S, h);
 }
@@ -691,6 +703,7 @@ __device__ __forceinline__ bool slot_to_pixel(const RenderParams &P, uint32_t sl
     return x < P.width && y < P.height;                 // main.wgsl:17
 }
 
+#ifdef RT_TU_SIMPLE
 // ---- variant 0: persistent wavefronts pulling pixel slots from a queue ----
 template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParams P) {
@@ -747,6 +760,9 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
     flush_tally<COUNT>(P, tl);
 }
 
+#endif  // RT_TU_SIMPLE
+
+#ifdef RT_TU_PHASED
 // ---- variant 2: persistent wavefronts, lanes scheduled by phase ----
 // Ray lengths differ wildly inside a wave (a sky ray visits 3 nodes, a ray through
 // the teapot 80), so a wave that traces "one ray per lane" waits for its slowest
@@ -1107,6 +1123,9 @@ __global__ __launch_bounds__(256) void rt_blend_frames(const RenderParams P, siz
     *dst = make_float4(acc.x, acc.y, acc.z, old.w);
 }
 
+#endif  // RT_TU_PHASED
+
+#ifdef RT_TU_SIMPLE
 // ---- variant 1: one wave per 8x8 tile (the reference's mapping) ----
 template <bool COUNT, bool AOV, bool SPH>
 __global__ __launch_bounds__(kBlock) void rt_render_tiles(const RenderParams P) {
@@ -1136,6 +1155,8 @@ __global__ __launch_bounds__(kBlock) void rt_render_tiles(const RenderParams P) 
     flush_tally<COUNT>(P, tl);
 }
 
+#endif  // RT_TU_SIMPLE
+
 template <typename K>
 hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const RenderParams &P) {
     hipLaunchKernelGGL(kernel, grid, dim3(kBlock), lds, stream, P);
@@ -1144,6 +1165,7 @@ hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const Ren
 
 }  // namespace
 
+#ifdef RT_TU_PHASED
 // Persistent grid size: the number of 256-thread workgroups of the given kernel
 // instance that are resident at once (register/LDS limited), so every wave
 // lives for the whole launch.
@@ -1176,26 +1198,57 @@ int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool ao
     return per_cu * prop.multiProcessorCount;
 }
 
-// Host-side launcher.  Dynamic LDS = stack_entries x 256 lanes x 4 B.
+// LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS); FMT: the node format
 template <bool COUNT, bool AOV, bool SPH>
-static hipError_t launch_variant(const RenderParams &P, int variant, dim3 tile_grid, dim3 persistent_grid, size_t lds, hipStream_t stream) {
-    if (variant == 1) return launch(rt_render_tiles<COUNT, AOV, SPH>, tile_grid, lds, stream, P);
-    if (variant == 0) return launch(rt_render_persistent<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
-    // LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS); Q8: 32-byte nodes
+static hipError_t launch_phased(const RenderParams &P, dim3 grid, size_t lds, hipStream_t stream) {
     const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
     const int fmt = P.node_wide ? (int)P.node_wide + 1 : (P.node_q8 ? 1 : 0);
     if (ldsm) {
-        if (fmt == 3) return launch(rt_render_phased<COUNT, AOV, SPH, true, 3>, persistent_grid, lds, stream, P);
-        if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, true, 2>, persistent_grid, lds, stream, P);
-        if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, true, 1>, persistent_grid, lds, stream, P);
-        return launch(rt_render_phased<COUNT, AOV, SPH, true, 0>, persistent_grid, lds, stream, P);
+        if (fmt == 3) return launch(rt_render_phased<COUNT, AOV, SPH, true, 3>, grid, lds, stream, P);
+        if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, true, 2>, grid, lds, stream, P);
+        if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, true, 1>, grid, lds, stream, P);
+        return launch(rt_render_phased<COUNT, AOV, SPH, true, 0>, grid, lds, stream, P);
     }
-    if (fmt == 3) return launch(rt_render_phased<COUNT, AOV, SPH, false, 3>, persistent_grid, lds, stream, P);
-    if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, false, 2>, persistent_grid, lds, stream, P);
-    if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, false, 1>, persistent_grid, lds, stream, P);
-    return launch(rt_render_phased<COUNT, AOV, SPH, false, 0>, persistent_grid, lds, stream, P);
+    if (fmt == 3) return launch(rt_render_phased<COUNT, AOV, SPH, false, 3>, grid, lds, stream, P);
+    if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, false, 2>, grid, lds, stream, P);
+    if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, false, 1>, grid, lds, stream, P);
+    return launch(rt_render_phased<COUNT, AOV, SPH, false, 0>, grid, lds, stream, P);
 }
 
+// variant 2 (and the blend of a multi-frame launch).  Lives in its own translation unit: see the Makefile on
+// -structurizecfg-skip-uniform-regions.
+hipError_t rt_launch_phased(const RenderParams &P, bool count, bool aov, bool spheres, unsigned blocks, size_t lds, hipStream_t stream) {
+    const dim3 grid(blocks);
+    const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
+    hipError_t e = hipSuccess;
+    switch (sel) {
+        case 0: e = launch_phased<false, false, false>(P, grid, lds, stream); break;
+        case 1: e = launch_phased<false, false, true>(P, grid, lds, stream); break;
+        case 2: e = launch_phased<false, true, false>(P, grid, lds, stream); break;
+        case 3: e = launch_phased<false, true, true>(P, grid, lds, stream); break;
+        case 4: e = launch_phased<true, false, false>(P, grid, lds, stream); break;
+        case 5: e = launch_phased<true, false, true>(P, grid, lds, stream); break;
+        case 6: e = launch_phased<true, true, false>(P, grid, lds, stream); break;
+        default: e = launch_phased<true, true, true>(P, grid, lds, stream); break;
+    }
+    if (e != hipSuccess || P.n_frames <= 1u) return e;
+    const size_t n_pixels = (size_t)P.local_rows * P.width;
+    if (n_pixels) rt_blend_frames<<<dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream>>>(P, n_pixels);
+    return hipGetLastError();
+}
+#endif  // RT_TU_PHASED
+
+#ifdef RT_TU_SIMPLE
+hipError_t rt_launch_phased(const RenderParams &P, bool count, bool aov, bool spheres, unsigned blocks, size_t lds, hipStream_t stream);
+
+// variants 0 and 1 (the A/B baselines)
+template <bool COUNT, bool AOV, bool SPH>
+static hipError_t launch_simple(const RenderParams &P, int variant, dim3 tile_grid, dim3 persistent_grid, size_t lds, hipStream_t stream) {
+    if (variant == 1) return launch(rt_render_tiles<COUNT, AOV, SPH>, tile_grid, lds, stream, P);
+    return launch(rt_render_persistent<COUNT, AOV, SPH>, persistent_grid, lds, stream, P);
+}
+
+// Host-side launcher.  Dynamic LDS = stack_entries x 256 lanes x 4 B.
 hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream) {
     const uint32_t tiles = P.tiles_x * P.local_bands;
     if (tiles == 0) return hipSuccess;
@@ -1206,21 +1259,18 @@ hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool
     uint32_t blocks = (uint32_t)persistent_blocks;
     if ((uint64_t)blocks > (chunks + 3) / 4) blocks = (uint32_t)((chunks + 3) / 4);
     if (blocks == 0) blocks = 1;
+    if (variant == 2) return rt_launch_phased(P, count, aov, spheres, blocks, lds, stream);
     dim3 pgrid(blocks);
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
-    hipError_t e = hipSuccess;
     switch (sel) {
-        case 0: e = launch_variant<false, false, false>(P, variant, tile_grid, pgrid, lds, stream); break;
-        case 1: e = launch_variant<false, false, true>(P, variant, tile_grid, pgrid, lds, stream); break;
-        case 2: e = launch_variant<false, true, false>(P, variant, tile_grid, pgrid, lds, stream); break;
-        case 3: e = launch_variant<false, true, true>(P, variant, tile_grid, pgrid, lds, stream); break;
-        case 4: e = launch_variant<true, false, false>(P, variant, tile_grid, pgrid, lds, stream); break;
-        case 5: e = launch_variant<true, false, true>(P, variant, tile_grid, pgrid, lds, stream); break;
-        case 6: e = launch_variant<true, true, false>(P, variant, tile_grid, pgrid, lds, stream); break;
-        default: e = launch_variant<true, true, true>(P, variant, tile_grid, pgrid, lds, stream); break;
+        case 0: return launch_simple<false, false, false>(P, variant, tile_grid, pgrid, lds, stream);
+        case 1: return launch_simple<false, false, true>(P, variant, tile_grid, pgrid, lds, stream);
+        case 2: return launch_simple<false, true, false>(P, variant, tile_grid, pgrid, lds, stream);
+        case 3: return launch_simple<false, true, true>(P, variant, tile_grid, pgrid, lds, stream);
+        case 4: return launch_simple<true, false, false>(P, variant, tile_grid, pgrid, lds, stream);
+        case 5: return launch_simple<true, false, true>(P, variant, tile_grid, pgrid, lds, stream);
+        case 6: return launch_simple<true, true, false>(P, variant, tile_grid, pgrid, lds, stream);
+        default: return launch_simple<true, true, true>(P, variant, tile_grid, pgrid, lds, stream);
     }
-    if (e != hipSuccess || P.n_frames <= 1u) return e;
-    const size_t n_pixels = (size_t)P.local_rows * P.width;
-    if (n_pixels) rt_blend_frames<<<dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream>>>(P, n_pixels);
-    return hipGetLastError();
 }
+#endif  // RT_TU_SIMPLE

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity run: random triangle soups (sizes, extents, offsets from the origin), random geometry
-transforms applied through rt_models_update (device refit), random cameras and materials; HIP path against the
-oracle's BRUTE-FORCE mode, bit for bit.  usage: python tests/checkers/fuzz_parity.py [--iters 40] [--seed 1]"""
+transforms applied through rt_models_update (device refit), random cameras and materials, and per case at random: spheres,
+a run of frames in one launch (rt_dispatch_frames / rt_dispatch_frames_static), an rt_group of 2-4 shards, the other kernel
+variants; HIP path against the oracle's BRUTE-FORCE mode, bit for bit.  usage: python tests/checkers/fuzz_parity.py [--iters 40] [--seed 1]"""
 import argparse, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,18 +15,22 @@ ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-tris", type=int, default=400, help="per geometry")
 ap.add_argument("--node-format", type=int, default=0, help="RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte, 2 32-byte binary nodes, 3 80-byte, 4 64-byte 8-ary nodes")
+ap.add_argument("--only", type=int, default=-1, help="run just this iteration (the random stream is still advanced through the others), with details")
+ap.add_argument("--force-aov", type=int, default=-1)
+ap.add_argument("--force-kernel", type=int, default=-1)
 args = ap.parse_args()
 rt = graft.load_package()
 rng = np.random.default_rng(args.seed)
 bad = 0
+total_rays = total_hits = 0
 for it in range(args.iters):
-    n_geo = int(rng.integers(1, 4))
+    n_geo = int(rng.integers(1, 4)) if rng.random() < 0.9 else int(rng.integers(17, 21))   # > 16 models: the kernel instance that reads materials from memory
     verts, idx, prims, mods = [], [], [], []
     centre = (rng.random(3) - 0.5) * 10.0 ** rng.integers(0, 5)
     spread = 10.0 ** rng.uniform(-1, 2)
     for g in range(n_geo):
-        n = int(rng.integers(1, args.max_tris))
-        size = spread * 10.0 ** rng.uniform(-2.5, -0.3)
+        n = int(rng.integers(1, args.max_tris if n_geo < 4 else max(2, args.max_tris // 8)))
+        size = spread * 10.0 ** rng.uniform(-2.2, 0.0)
         c = centre + (rng.random((n, 1, 3)) - 0.5) * 2 * spread
         p = (c + (rng.random((n, 3, 3)) - 0.5) * 2 * size).astype(np.float32)
         v = np.zeros(3 * n, obj_loader.VERTEX_DTYPE)
@@ -70,20 +75,67 @@ for it in range(args.iters):
     yaw = float(np.arctan2(d[2], d[0]) + rng.uniform(-0.3, 0.3))
     pitch = float(np.clip(np.arcsin(d[1]) + rng.uniform(-0.3, 0.3), -1.5, 1.5))
     scene = obj_loader.Scene(V, I, P, M)
-    want, want_hits, cnt = oracle.OracleScene(scene, transforms=T, build_bvh=False).render(
-        oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=0, want_hits=True)
-    with rt.Context(0) as ctx:
+    S = None
+    if rng.random() < 0.35:                              # spheres (build-defined primitive)
+        ns = int(rng.integers(1, 120))
+        S = np.zeros(ns, obj_loader.SPHERE_DTYPE)
+        S["center"] = (centre + (rng.random((ns, 3)) - 0.5) * 2 * spread).astype(np.float32)
+        S["radius"] = (spread * 10.0 ** rng.uniform(-2.0, -0.5, ns)).astype(np.float32)
+        S["model"] = rng.integers(0, n_geo, ns)
+    n_frames = int(rng.integers(2, 4)) if rng.random() < 0.3 else 1
+    shards = int(rng.integers(2, 5)) if rng.random() < 0.25 else 1
+    kernel = int(rng.choice([2, 2, 2, 0, 1]))
+    counting = rng.random() < 0.15                       # the counting instances of the kernels
+    static = n_frames > 1 and shards == 1 and kernel == 2 and rng.random() < 0.5
+    if args.only >= 0 and it != args.only:
+        continue
+    if args.force_kernel >= 0:
+        kernel = args.force_kernel
+    osc = oracle.OracleScene(scene, transforms=T, spheres=S, build_bvh=False)
+    if n_frames == 1:
+        want, want_hits, cnt = osc.render(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=0, want_hits=True)
+    else:                                                # the cold-start frame sequence of src/app.rs:78-96
+        kw.pop("frame")
+        want, cnt = osc.render_frames(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), n_frames, mode=0)
+        want_hits = None
+    with (rt.Group([0] * shards) if shards > 1 else rt.Context(0)) as ctx:
         ctx.set_option(rt.RT_OPT_NODE_FORMAT, args.node_format)
+        ctx.set_option(rt.RT_OPT_KERNEL, kernel)
+        ctx.set_option(rt.RT_OPT_COUNT_TRAVERSAL, int(counting))
         ctx.scene_upload(V, I, P, M)
+        if S is not None:
+            ctx.spheres_upload(S)
         ctx.models_update(M, transforms=T)               # device refit of the tree built for the untransformed scene
-        ctx.set_option(rt.RT_OPT_AOV, 1)
+        aov = n_frames == 1 and shards == 1
+        if args.force_aov >= 0 and shards == 1:
+            aov = bool(args.force_aov)
+        if aov:
+            ctx.set_option(rt.RT_OPT_AOV, 1)
         ctx.accum_resize(w, h)
-        ctx.dispatch(rt.make_uniform(w, h, cam, yaw, pitch, **kw))
-        got, hits, st = ctx.accum_download(), ctx.aov_download(), ctx.stats()
+        u = rt.make_uniform(w, h, cam, yaw, pitch, **kw)
+        if n_frames == 1:
+            ctx.dispatch(u)
+        else:
+            u["frame"] = 0                               # cold start, src/main.rs:76-77
+            u["accumulation_frame"] = 1
+            (ctx.dispatch_frames_static if static else ctx.dispatch_frames)(u, n_frames)
+        got, st = ctx.accum_download(), ctx.stats()
+        hits = ctx.aov_download() if aov else None
     same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
-    ok = st.rays == cnt.rays and np.array_equal(hits, want_hits) and bool(same.all())
-    hit_frac = float((want_hits[..., 0] != 0xFFFFFFFF).mean())
-    print(f"iter {it}: {len(I) // 3} tris in {n_geo} geometries, {w}x{h}, {kw}, primary hit fraction {hit_frac:.2f}, rays {cnt.rays}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    if counting and cnt.rays and (st.node_visits == 0 or st.wave_steps == 0):
+        print('  counting instance counted nothing'); bad += 1
+    ok = st.rays == cnt.rays and (hits is None or np.array_equal(hits, want_hits)) and bool(same.all())
+    if args.only >= 0:
+        diff = ~same.all(axis=-1)
+        ys, xs = np.nonzero(diff)
+        print(f"  rays device {st.rays} oracle {cnt.rays}; {int(diff.sum())} of {diff.size} pixels differ; first: {[(int(x), int(y)) for x, y in zip(xs[:8], ys[:8])]}")
+        for x, y in list(zip(xs[:4], ys[:4])):
+            print(f"   ({x},{y}): device {got[y, x]} oracle {want[y, x]}")
+    total_rays += int(cnt.rays)
+    total_hits += int(cnt.hits)
+    what = f"{len(I) // 3} tris in {n_geo} geometries" + (f" + {len(S)} spheres" if S is not None else "") + \
+           (f", {n_frames} frames" + (" (static)" if static else "") if n_frames > 1 else "") + (f", group of {shards}" if shards > 1 else "") + f", kernel {kernel}" + (" counting" if counting else "")
+    print(f"iter {it}: {what}, {w}x{h}, {kw}, rays {cnt.rays}, hits {cnt.hits}: {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
-print("fuzz:", "all identical" if bad == 0 else f"{bad} mismatches")
+print(f"fuzz: {args.iters} cases, {total_rays} rays, {total_hits} of them hit something;", "all identical" if bad == 0 else f"{bad} mismatches")
 sys.exit(1 if bad else 0)
