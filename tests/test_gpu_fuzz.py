@@ -26,3 +26,11 @@ def test_fuzz_against_brute_force(node_format):
     tail = "\n".join(r.stdout.splitlines()[-5:])
     assert r.returncode == 0, f"{tail}\n{r.stderr[-2000:]}"
     assert "all identical" in r.stdout.splitlines()[-1], tail
+
+
+def test_flag_and_no_flag_builds_render_the_same_bits_at_size():
+    """tools/ab_flag_bits.py --quick: C2, C3 (binary and 8-ary nodes) and C4 (8-ary and binary nodes, spheres) at full size from
+    librt_amd.so and from librt_amd_noflag.so (no uniform-branch flag anywhere): same accumulation buffers, same ray counts."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab_flag_bits.py"), "--quick"], capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, f"{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
+    assert r.stdout.count("identical") == 5 and "DIFFERENT" not in r.stdout, r.stdout
