@@ -484,6 +484,14 @@ class Group:
         sp = np.ascontiguousarray(spheres)
         _check(lib().rt_group_spheres_upload(self.handle, sp.ctypes.data, len(sp)))
 
+    def textures_upload(self, images):
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        arr = (RtTexture * max(1, len(imgs)))()
+        for i, im in enumerate(imgs):
+            assert im.ndim == 3 and im.shape[2] == 4
+            arr[i].rgba8, arr[i].width, arr[i].height = im.ctypes.data, im.shape[1], im.shape[0]
+        _check(lib().rt_group_textures_upload(self.handle, arr, len(imgs)))
+
     def models_update(self, models, transforms=None):
         m = np.ascontiguousarray(models)
         t = None if transforms is None else np.ascontiguousarray(transforms, np.float32)

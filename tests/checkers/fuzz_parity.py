@@ -74,7 +74,13 @@ for it in range(args.iters):
     d = d / max(np.linalg.norm(d), 1e-20)
     yaw = float(np.arctan2(d[2], d[0]) + rng.uniform(-0.3, 0.3))
     pitch = float(np.clip(np.arcsin(d[1]) + rng.uniform(-0.3, 0.3), -1.5, 1.5))
-    scene = obj_loader.Scene(V, I, P, M)
+    textures = []
+    if rng.random() < 0.25:                              # textures: index 0 = none, k = texture k - 1, beyond = black
+        textures = [rng.integers(0, 256, (int(rng.integers(1, 10)), int(rng.integers(1, 10)), 4), dtype=np.uint8) for _ in range(int(rng.integers(1, 4)))]
+        M["diffuse_texture"] = rng.integers(0, len(textures) + 2, n_geo)
+        M["normal_texture"] = rng.integers(0, len(textures) + 2, n_geo)
+        V["uv"] = (rng.random((len(V), 2)) * 1.4 - 0.2).astype(np.float32)          # some outside [0, 1]: clamp to edge
+    scene = obj_loader.Scene(V, I, P, M, textures=textures)
     S = None
     if rng.random() < 0.35:                              # spheres (build-defined primitive)
         ns = int(rng.integers(1, 120))
@@ -105,6 +111,8 @@ for it in range(args.iters):
         ctx.scene_upload(V, I, P, M)
         if S is not None:
             ctx.spheres_upload(S)
+        if textures:
+            ctx.textures_upload(textures)
         ctx.models_update(M, transforms=T)               # device refit of the tree built for the untransformed scene
         aov = n_frames == 1 and shards == 1
         if args.force_aov >= 0 and shards == 1:
@@ -133,7 +141,7 @@ for it in range(args.iters):
             print(f"   ({x},{y}): device {got[y, x]} oracle {want[y, x]}")
     total_rays += int(cnt.rays)
     total_hits += int(cnt.hits)
-    what = f"{len(I) // 3} tris in {n_geo} geometries" + (f" + {len(S)} spheres" if S is not None else "") + \
+    what = f"{len(I) // 3} tris in {n_geo} geometries" + (f" + {len(S)} spheres" if S is not None else "") + (f" + {len(textures)} textures" if textures else "") + \
            (f", {n_frames} frames" + (" (static)" if static else "") if n_frames > 1 else "") + (f", group of {shards}" if shards > 1 else "") + f", kernel {kernel}" + (" counting" if counting else "")
     print(f"iter {it}: {what}, {w}x{h}, {kw}, rays {cnt.rays}, hits {cnt.hits}: {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
