@@ -217,7 +217,8 @@ int rt_set_option(rt_context *ctx, int key, int64_t value);
  * builds the acceleration structure (host SAH BVH build + repack, the part
  * the Vulkan driver does for the reference at src/scene.rs:56-64).
  * `transforms` = n_primitives row-major 3x4 matrices, or NULL for identity
- * (src/scene.rs:53-54). */
+ * (src/scene.rs:53-54).  A triangle or sphere with a NaN / infinite corner, centre or radius (after its transform) is accepted and is
+ * never hit — what the arithmetic contract's tests give for it — and does not disturb the rest of the scene. */
 int rt_scene_upload(rt_context *ctx,
                     const RtVertex *vertices, uint64_t n_vertices,
                     const uint32_t *indices, uint64_t n_indices,

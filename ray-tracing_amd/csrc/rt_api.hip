@@ -556,9 +556,10 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     std::vector<rt_host::Aabb> boxes(n_prims);
     for (uint64_t t = 0; t < n_tris; t++) {
         const float *c = &corners[9 * t];
+        const bool finite = rt_all_finite(c, 9);          // else: never hit, and kept out of the tree's boxes (rt_pack.h RT_EMPTY_BOX)
         for (int k = 0; k < 3; k++) {
-            boxes[t].lo[k] = fminf(c[k], fminf(c[3 + k], c[6 + k]));
-            boxes[t].hi[k] = fmaxf(c[k], fmaxf(c[3 + k], c[6 + k]));
+            boxes[t].lo[k] = finite ? fminf(c[k], fminf(c[3 + k], c[6 + k])) : RT_EMPTY_BOX;
+            boxes[t].hi[k] = finite ? fmaxf(c[k], fmaxf(c[3 + k], c[6 + k])) : -RT_EMPTY_BOX;
         }
     }
     for (uint64_t i = 0; i < ctx->hs->spheres.size(); i++) {
@@ -566,7 +567,11 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
         if (!(sp.radius > 0.0f)) return fail(RT_ERR_INVALID_ARGUMENT, "sphere %llu: radius must be positive", (unsigned long long)i);
         if (sp.model >= ctx->hs->models.size()) return fail(RT_ERR_INVALID_ARGUMENT, "sphere %llu: model index out of range", (unsigned long long)i);
         const float r = sp.radius * 1.0001f + 1e-6f;   // the quadratic's roots are not exact
-        for (int k = 0; k < 3; k++) { boxes[n_tris + i].lo[k] = sp.center[k] - r; boxes[n_tris + i].hi[k] = sp.center[k] + r; }
+        const bool finite = rt_all_finite(sp.center, 3) && rt_all_finite(&r, 1);
+        for (int k = 0; k < 3; k++) {
+            boxes[n_tris + i].lo[k] = finite ? sp.center[k] - r : RT_EMPTY_BOX;
+            boxes[n_tris + i].hi[k] = finite ? sp.center[k] + r : -RT_EMPTY_BOX;
+        }
     }
     // Node format (RT_OPT_NODE_FORMAT).  The compact formats (8-bit plane offsets) need the scene's extent to fit their scale range.
     rt_host::Aabb scene_box;

@@ -19,6 +19,18 @@ RT_HD float rt_pad_hi(float v) { return v + (fabsf(v) * 4.76837158e-7f + 1e-30f)
 #endif
 RT_HD float rt_prim_pad(float scene_max_abs) { return scene_max_abs <= 3.0e38f ? scene_max_abs * RT_PRIM_PAD_SCALE : 0.0f; }
 
+// A primitive with a non-finite corner (NaN or +-inf after the geometry transform) can never be hit: every comparison of the
+// contract's triangle / sphere test fails on the NaNs it produces (the oracle's brute force agrees, tests/checkers/fuzz_parity.py).
+// Its box must not reach the tree — one infinite plane poisons the corner of every ancestor and culls the finite geometry
+// beside it — so such a primitive gets this EMPTY box: inverted and finite, ignored by every min / max union and packed
+// as an inverted child box (lo offset saturated, hi offset 0) that no ray enters.
+#define RT_EMPTY_BOX 3.0e38f
+RT_HD bool rt_all_finite(const float *v, int n) {
+    for (int i = 0; i < n; i++)
+        if (!(v[i] >= -3.0e38f && v[i] <= 3.0e38f)) return false;
+    return true;
+}
+
 // x >= 0 → the f16 bit pattern nearest to x from below (up = false) or above (up = true).
 // Above saturates to +inf, below to 65504; a non-zero upper bound is never an f16
 // denormal, so a flush-to-zero mode cannot shrink a box.

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void rt_refit_tris(DevTri *__restrict__ tris, 
         // spheres do not move with a geometry; the box is the builder's (rt_api.hip build_and_upload)
         const float r = t.e1x * 1.0001f + 1e-6f;
         const float c[3] = {t.ax, t.ay, t.az};
-        for (int k = 0; k < 3; k++) { b.lo[k] = c[k] - r; b.hi[k] = c[k] + r; }
+        const bool finite = rt_all_finite(c, 3) && rt_all_finite(&r, 1);
+        for (int k = 0; k < 3; k++) { b.lo[k] = finite ? c[k] - r : RT_EMPTY_BOX; b.hi[k] = finite ? c[k] + r : -RT_EMPTY_BOX; }
     } else {
         const DevShade &s = shade[slot];
         float c[9];
@@ -45,9 +46,10 @@ __global__ __launch_bounds__(256) void rt_refit_tris(DevTri *__restrict__ tris, 
         t.e1x = c[3] - c[0]; t.e1y = c[4] - c[1]; t.e1z = c[5] - c[2];
         t.e2x = c[6] - c[0]; t.e2y = c[7] - c[1]; t.e2z = c[8] - c[2];
         tris[slot] = t;
+        const bool finite = rt_all_finite(c, 9);            // a non-finite corner: the empty box, as the host build gives it (rt_pack.h)
         for (int k = 0; k < 3; k++) {
-            b.lo[k] = fminf(c[k], fminf(c[3 + k], c[6 + k]));
-            b.hi[k] = fmaxf(c[k], fmaxf(c[3 + k], c[6 + k]));
+            b.lo[k] = finite ? fminf(c[k], fminf(c[3 + k], c[6 + k])) : RT_EMPTY_BOX;
+            b.hi[k] = finite ? fmaxf(c[k], fmaxf(c[3 + k], c[6 + k])) : -RT_EMPTY_BOX;
         }
     }
     for (int k = 0; k < 3; k++) { b.lo[k] -= prim_pad; b.hi[k] += prim_pad; }      // as the host build widens them (rt_pack.h rt_prim_pad)

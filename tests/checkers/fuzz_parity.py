@@ -26,6 +26,7 @@ total_rays = total_hits = 0
 for it in range(args.iters):
     n_geo = int(rng.integers(1, 4)) if rng.random() < 0.9 else int(rng.integers(17, 21))   # > 16 models: the kernel instance that reads materials from memory
     verts, idx, prims, mods = [], [], [], []
+    notes = set()
     centre = (rng.random(3) - 0.5) * 10.0 ** rng.integers(0, 5)
     spread = 10.0 ** rng.uniform(-1, 2)
     for g in range(n_geo):
@@ -33,6 +34,12 @@ for it in range(args.iters):
         size = spread * 10.0 ** rng.uniform(-2.2, 0.0)
         c = centre + (rng.random((n, 1, 3)) - 0.5) * 2 * spread
         p = (c + (rng.random((n, 3, 3)) - 0.5) * 2 * size).astype(np.float32)
+        if n > 4 and rng.random() < 0.15:                # exact duplicates: equal t, the tie goes to the lower index-buffer position
+            k = rng.integers(0, n, max(1, n // 10)); p[k] = p[rng.integers(0, n, len(k))]; notes.add('duplicates')
+        if rng.random() < 0.1:                           # degenerate triangles (two equal corners): never hit
+            k = rng.integers(0, n, max(1, n // 20)); p[k, 1] = p[k, 0]; notes.add('degenerate')
+        if rng.random() < 0.02:                          # a non-finite corner: that triangle never hits, the rest of the scene does
+            p[int(rng.integers(0, n)), int(rng.integers(0, 3)), int(rng.integers(0, 3))] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]; notes.add('non-finite')
         v = np.zeros(3 * n, obj_loader.VERTEX_DTYPE)
         v["position"] = p.reshape(-1, 3)
         nr = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
@@ -66,6 +73,13 @@ for it in range(args.iters):
     if rng.random() < 0.7:
         T += ((rng.random((n_geo, 12)) - 0.5) * 0.4).astype(np.float32)
         T[:, 3::4] += ((rng.random((n_geo, 3)) - 0.5) * spread).astype(np.float32)
+    T0 = None
+    if rng.random() < 0.3:                               # an earlier update first: two refits in a row
+        T0 = T + ((rng.random((n_geo, 12)) - 0.5) * 0.2).astype(np.float32)
+    if rng.random() < 0.1:                               # a long way: out of the 8-ary formats' corner grid / scale range -> rebuild on the host
+        T[:, 3::4] += ((rng.random((n_geo, 3)) - 0.5) * spread * 60).astype(np.float32); notes.add('far move')
+    refit = int(rng.choice([2, 2, 2, 1, 0]))             # RT_OPT_REFIT: device refit, host refit, rebuild
+    cw = rng.random() < 0.2                              # RT_OPT_FRONT_FACE_CW
     w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
     cam = centre + (rng.random(3) - 0.5) * 3 * spread
     kw = dict(max_bounces=int(rng.integers(0, 6)), samples=int(rng.integers(1, 4)), fov=float(rng.uniform(0.3, 2.5)),
@@ -98,6 +112,7 @@ for it in range(args.iters):
     if args.force_kernel >= 0:
         kernel = args.force_kernel
     osc = oracle.OracleScene(scene, transforms=T, spheres=S, build_bvh=False)
+    oracle.lib().oracle_scene_set_front_face_cw(osc.handle, int(cw))
     if n_frames == 1:
         want, want_hits, cnt = osc.render(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=0, want_hits=True)
     else:                                                # the cold-start frame sequence of src/app.rs:78-96
@@ -108,11 +123,15 @@ for it in range(args.iters):
         ctx.set_option(rt.RT_OPT_NODE_FORMAT, args.node_format)
         ctx.set_option(rt.RT_OPT_KERNEL, kernel)
         ctx.set_option(rt.RT_OPT_COUNT_TRAVERSAL, int(counting))
+        ctx.set_option(rt.RT_OPT_REFIT, refit)
+        ctx.set_option(rt.RT_OPT_FRONT_FACE_CW, int(cw))
         ctx.scene_upload(V, I, P, M)
         if S is not None:
             ctx.spheres_upload(S)
         if textures:
             ctx.textures_upload(textures)
+        if T0 is not None:
+            ctx.models_update(M, transforms=T0)
         ctx.models_update(M, transforms=T)               # device refit of the tree built for the untransformed scene
         aov = n_frames == 1 and shards == 1
         if args.force_aov >= 0 and shards == 1:
@@ -142,7 +161,7 @@ for it in range(args.iters):
     total_rays += int(cnt.rays)
     total_hits += int(cnt.hits)
     what = f"{len(I) // 3} tris in {n_geo} geometries" + (f" + {len(S)} spheres" if S is not None else "") + (f" + {len(textures)} textures" if textures else "") + \
-           (f", {n_frames} frames" + (" (static)" if static else "") if n_frames > 1 else "") + (f", group of {shards}" if shards > 1 else "") + f", kernel {kernel}" + (" counting" if counting else "")
+           (f", {n_frames} frames" + (" (static)" if static else "") if n_frames > 1 else "") + (f", group of {shards}" if shards > 1 else "") + f", kernel {kernel}, refit {refit}" + (" counting" if counting else "") + (" cw" if cw else "") + (" 2 updates" if T0 is not None else "") + "".join(" " + x for x in sorted(notes))
     print(f"iter {it}: {what}, {w}x{h}, {kw}, rays {cnt.rays}, hits {cnt.hits}: {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
 print(f"fuzz: {args.iters} cases, {total_rays} rays, {total_hits} of them hit something;", "all identical" if bad == 0 else f"{bad} mismatches")

@@ -11,9 +11,10 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, assert_images_identical
 
 pytestmark = pytest.mark.gpu
 
@@ -34,3 +35,49 @@ def test_flag_and_no_flag_builds_render_the_same_bits_at_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ab_flag_bits.py"), "--quick"], capture_output=True, text=True, timeout=280, cwd=ROOT)
     assert r.returncode == 0, f"{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
     assert r.stdout.count("identical") == 5 and "DIFFERENT" not in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("node_format", [1, 2, 3, 4])
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_non_finite_corner_hides_nothing(rt, oracle_mod, obj_loader, node_format, bad):
+    """A triangle (or sphere) with a NaN / infinite corner is never hit, and must not take the finite geometry beside it out of the
+    tree (found by the checker: one infinite plane used to poison the boxes of every ancestor).  Upload, host refit, device refit."""
+    rng = np.random.default_rng(7)
+    n = 300
+    c = (rng.random((n, 1, 3)) - 0.5) * 4.0
+    p = (c + (rng.random((n, 3, 3)) - 0.5) * 0.8).astype(np.float32)
+    p[17, 1, 2] = bad
+    p[203, 0, 0] = bad
+    V = np.zeros(3 * n, obj_loader.VERTEX_DTYPE)
+    V["position"] = p.reshape(-1, 3)
+    V["normal"] = (0.0, 1.0, 0.0)
+    I = np.arange(3 * n, dtype=np.uint32)
+    P = np.zeros(1, obj_loader.PRIMITIVE_DTYPE)
+    P[0] = (0, 3 * n, 0, 3 * n, 0)
+    M = np.zeros(1, obj_loader.MODEL_DTYPE)
+    M["diffuse_color"] = (0.8, 0.6, 0.4)
+    M["roughness"] = 1.0
+    S = np.zeros(3, obj_loader.SPHERE_DTYPE)
+    S["center"] = [(0.5, 0.5, 0.5), (bad, 0.0, 0.0), (-1.0, 0.2, 0.3)]
+    S["radius"] = [0.3, 0.5, np.inf if np.isinf(bad) else 0.2]
+    T = np.array([[1.1, 0.1, 0, 0.2, 0, 0.9, 0.1, -0.1, 0.05, 0, 1, 0.3]], np.float32)
+    w, h = 64, 48
+    kw = dict(max_bounces=3, samples=2)
+    scene = obj_loader.Scene(V, I, P, M)
+    for refit in (2, 1):
+        want, want_hits, cnt = oracle_mod.OracleScene(scene, transforms=T, spheres=S, build_bvh=False).render(
+            oracle_mod.make_uniform(w, h, (0.0, 0.0, -6.0), np.pi / 2, 0.0, **kw), mode=0, want_hits=True)
+        assert cnt.hits > 1000
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.RT_OPT_NODE_FORMAT, node_format)
+            ctx.set_option(rt.RT_OPT_REFIT, refit)
+            ctx.set_option(rt.RT_OPT_AOV, 1)
+            ctx.scene_upload(V, I, P, M)
+            ctx.spheres_upload(S)
+            ctx.models_update(M, transforms=T)
+            ctx.accum_resize(w, h)
+            ctx.dispatch(rt.make_uniform(w, h, (0.0, 0.0, -6.0), np.pi / 2, 0.0, **kw))
+            got, hits, st = ctx.accum_download(), ctx.aov_download(), ctx.stats()
+        assert st.rays == cnt.rays
+        assert np.array_equal(hits, want_hits)
+        assert_images_identical(got, want, f"non-finite corner {bad}, format {node_format}, refit {refit}")
