@@ -34,18 +34,42 @@ for it in range(args.iters):
         size = spread * 10.0 ** rng.uniform(-2.2, 0.0)
         c = centre + (rng.random((n, 1, 3)) - 0.5) * 2 * spread
         p = (c + (rng.random((n, 3, 3)) - 0.5) * 2 * size).astype(np.float32)
+        kind = rng.random()
+        mesh_idx = None
+        if kind < 0.2 and n >= 8:                        # a height field with SHARED vertices: rays through shared edges and corners
+            gw = int(rng.integers(2, max(3, int(np.sqrt(n / 2)) + 2))); gh = max(2, n // (2 * (gw - 1)) + 1)
+            gx, gz = np.meshgrid(np.linspace(-1, 1, gw), np.linspace(-1, 1, gh), indexing="xy")
+            gy = (rng.random((gh, gw)) - 0.5) * rng.uniform(0, 0.6)
+            grid = (centre + np.stack([gx, gy, gz], -1).reshape(-1, 3) * spread).astype(np.float32)
+            q = np.arange((gh - 1) * (gw - 1)); r0 = q // (gw - 1) * gw + q % (gw - 1)
+            mesh_idx = np.stack([r0, r0 + 1, r0 + gw, r0 + 1, r0 + gw + 1, r0 + gw], -1).reshape(-1).astype(np.uint32)
+            notes.add('mesh')
+        elif kind < 0.3:                                 # one giant quad under / through everything (C3's ground plane)
+            e = spread * rng.uniform(5, 200)
+            y = float(centre[1] - spread * rng.uniform(0, 1))
+            quad = np.array([[-e, y, -e], [e, y, -e], [e, y, e], [-e, y, -e], [e, y, e], [-e, y, e]], np.float64) + [centre[0], 0, centre[2]]
+            p = np.concatenate([p, quad.reshape(2, 3, 3).astype(np.float32)]); n += 2
+            notes.add('giant quad')
         if n > 4 and rng.random() < 0.15:                # exact duplicates: equal t, the tie goes to the lower index-buffer position
             k = rng.integers(0, n, max(1, n // 10)); p[k] = p[rng.integers(0, n, len(k))]; notes.add('duplicates')
         if rng.random() < 0.1:                           # degenerate triangles (two equal corners): never hit
             k = rng.integers(0, n, max(1, n // 20)); p[k, 1] = p[k, 0]; notes.add('degenerate')
         if rng.random() < 0.02:                          # a non-finite corner: that triangle never hits, the rest of the scene does
             p[int(rng.integers(0, n)), int(rng.integers(0, 3)), int(rng.integers(0, 3))] = [np.nan, np.inf, -np.inf][int(rng.integers(0, 3))]; notes.add('non-finite')
-        v = np.zeros(3 * n, obj_loader.VERTEX_DTYPE)
-        v["position"] = p.reshape(-1, 3)
-        nr = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
-        nr /= np.maximum(np.linalg.norm(nr, axis=1, keepdims=True), 1e-20)
-        v["normal"] = np.repeat(nr.astype(np.float32), 3, axis=0)
-        prims.append((sum(len(x) for x in verts), 3 * n, sum(len(x) for x in idx), 3 * n, g))
+        if mesh_idx is not None:
+            v = np.zeros(len(grid), obj_loader.VERTEX_DTYPE)
+            v["position"] = grid
+            v["normal"] = (rng.random((len(grid), 3)) - 0.5).astype(np.float32) + (0, 1, 0)      # un-normalised, interpolated (main.wgsl:95)
+            gi = mesh_idx
+        else:
+            v = np.zeros(3 * n, obj_loader.VERTEX_DTYPE)
+            v["position"] = p.reshape(-1, 3)
+            with np.errstate(all="ignore"):
+                nr = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+                nr /= np.maximum(np.linalg.norm(nr, axis=1, keepdims=True), 1e-20)
+            v["normal"] = np.repeat(np.nan_to_num(nr).astype(np.float32), 3, axis=0)
+            gi = np.arange(3 * n, dtype=np.uint32)
+        prims.append((sum(len(x) for x in verts), len(v), sum(len(x) for x in idx), len(gi), g))
         m = np.zeros(1, obj_loader.MODEL_DTYPE)
         m["tag"] = 1 if rng.random() < 0.25 else 0
         m["diffuse_color"] = rng.random(3)
@@ -59,7 +83,7 @@ for it in range(args.iters):
         m["index_start"] = prims[-1][2]
         mods.append(m)
         verts.append(v)
-        idx.append(np.arange(3 * n, dtype=np.uint32))
+        idx.append(gi)
     V = np.zeros(sum(len(x) for x in verts), obj_loader.VERTEX_DTYPE)
     o = 0
     for v in verts:
@@ -69,6 +93,9 @@ for it in range(args.iters):
     for g, t in enumerate(prims): P[g] = t
     M = np.zeros(n_geo, obj_loader.MODEL_DTYPE)
     for g, m in enumerate(mods): M[g] = m[0]
+    if n_geo > 1 and rng.random() < 0.3:                 # src/scene.rs:141-147: a geometry names its transform by offset
+        P["transformation_offset"] = rng.permutation(n_geo) if rng.random() < 0.5 else rng.integers(0, n_geo, n_geo)
+        notes.add('offsets')
     T = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), (n_geo, 1))
     if rng.random() < 0.7:
         T += ((rng.random((n_geo, 12)) - 0.5) * 0.4).astype(np.float32)
@@ -82,8 +109,9 @@ for it in range(args.iters):
     cw = rng.random() < 0.2                              # RT_OPT_FRONT_FACE_CW
     w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
     cam = centre + (rng.random(3) - 0.5) * 3 * spread
-    kw = dict(max_bounces=int(rng.integers(0, 6)), samples=int(rng.integers(1, 4)), fov=float(rng.uniform(0.3, 2.5)),
-              flags=int(rng.integers(0, 2)), frame=int(rng.integers(1, 2**32)))
+    kw = dict(max_bounces=int(rng.integers(0, 6)), samples=int(rng.integers(1, 4)) if rng.random() < 0.97 else 0, fov=float(rng.uniform(0.3, 2.5)),
+              flags=int(rng.integers(0, 2)), frame=int(rng.integers(1, 2**32)), exposure=float(rng.choice([1.0, rng.uniform(0.1, 4.0)])),
+              environment=float(rng.choice([1.0, rng.uniform(0.0, 3.0)])))
     d = centre - cam                                     # look at the soup (ray.wgsl:52-58), with some jitter
     d = d / max(np.linalg.norm(d), 1e-20)
     yaw = float(np.arctan2(d[2], d[0]) + rng.uniform(-0.3, 0.3))
