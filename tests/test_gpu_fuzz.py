@@ -81,3 +81,14 @@ def test_non_finite_corner_hides_nothing(rt, oracle_mod, obj_loader, node_format
         assert st.rays == cnt.rays
         assert np.array_equal(hits, want_hits)
         assert_images_identical(got, want, f"non-finite corner {bad}, format {node_format}, refit {refit}")
+
+
+@pytest.mark.parametrize("node_format", [0, 3, 4])
+def test_fuzz_sessions_against_brute_force(node_format):
+    """tests/checkers/fuzz_session.py: contexts and groups that live through random call sequences (re-uploads, updates, resizes,
+    option changes, all three dispatch entry points) with the oracle's brute force shadowing the accumulation buffer."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checkers", "fuzz_session.py"), "--sessions", "200",
+                        "--seed", str(40 + node_format), "--node-format", str(node_format)], capture_output=True, text=True, timeout=280, cwd=ROOT)
+    tail = "\n".join(r.stdout.splitlines()[-5:])
+    assert r.returncode == 0, f"{tail}\n{r.stderr[-2000:]}"
+    assert "all identical" in r.stdout.splitlines()[-1], tail
