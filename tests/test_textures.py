@@ -182,3 +182,95 @@ def test_textured_scene_matches_oracle(rt, oracle_mod, obj_loader, textured_scen
     s2.models = m
     plain, _, _ = oracle_mod.OracleScene(s2).render(oracle_mod.make_uniform(w, h, (0.3, 2.2, -2.8), 1.45, **args), mode=1)
     assert not np.array_equal(plain, want)
+
+
+def _png_bytes(rng, w, h, ctype, depth, pixels, plte=None, trns=None):
+    """A PNG written by hand: every row gets a random filter type (0-4, applied here as the spec defines them), the compressed
+    stream is cut into several IDAT chunks, ancillary chunks are sprinkled in."""
+    import struct, zlib
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bits = channels * depth
+    stride, bpp = (w * bits + 7) // 8, max(1, bits // 8)
+    rows = []
+    for y in range(h):
+        if depth == 8:
+            rows.append(bytes(pixels[y].reshape(-1).astype(np.uint8)))
+        else:                                   # packed samples, most significant first
+            acc, out, nb = 0, bytearray(), 0
+            for v in pixels[y].reshape(-1):
+                acc = (acc << depth) | int(v); nb += depth
+                if nb == 8:
+                    out.append(acc); acc = nb = 0
+            if nb:
+                out.append(acc << (8 - nb))
+            rows.append(bytes(out))
+    raw = bytearray()
+    prev = bytes(stride)
+    for row in rows:
+        ft = int(rng.integers(0, 5))
+        f = bytearray(stride)
+        for i in range(stride):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if ft == 0: pred = 0
+            elif ft == 1: pred = a
+            elif ft == 2: pred = b
+            elif ft == 3: pred = (a + b) // 2
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+            f[i] = (row[i] - pred) & 255
+        raw.append(ft); raw += f
+        prev = row
+    z = zlib.compress(bytes(raw), int(rng.integers(0, 10)))
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if rng.random() < 0.5:
+        out += chunk(b"gAMA", struct.pack(">I", 45455))
+    if plte is not None:
+        out += chunk(b"PLTE", bytes(plte.reshape(-1)))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    cuts = sorted(set(int(x) for x in rng.integers(0, len(z) + 1, int(rng.integers(0, 4)))) | {0, len(z)})
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        out += chunk(b"IDAT", z[a:b])
+    if rng.random() < 0.5:
+        out += chunk(b"tEXt", b"Comment\x00fuzz")
+    return out + chunk(b"IEND", b"")
+
+
+def test_png_decoder_random_files_against_pil(rt, tmp_path):
+    """Hand-written PNGs of every 8-bit-or-less colour type / depth the decoder takes (grey 1/2/4/8, RGB 8, palette 1/2/4/8 with and
+    without tRNS, grey+alpha 8, RGBA 8), random sizes, a random filter per row, split IDAT: host/image_decode.cpp == PIL."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    kinds = [(0, 1), (0, 2), (0, 4), (0, 8), (2, 8), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (6, 8)]
+    names = []
+    for i in range(66):
+        ctype, depth = kinds[i % len(kinds)]
+        w, h = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+        channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+        plte = trns = None
+        if ctype == 3:
+            n_pal = int(rng.integers(1, (1 << depth) + 1))
+            plte = rng.integers(0, 256, (n_pal, 3), dtype=np.uint8)
+            pixels = rng.integers(0, n_pal, (h, w, 1))
+            if rng.random() < 0.5:
+                trns = rng.integers(0, 256, int(rng.integers(1, n_pal + 1)), dtype=np.uint8)
+        else:
+            pixels = rng.integers(0, 1 << depth, (h, w, channels))
+        name = f"f{i}_{ctype}_{depth}"
+        (tmp_path / f"{name}.png").write_bytes(_png_bytes(rng, w, h, ctype, depth, pixels, plte, trns))
+        names.append(name)
+    mtl = "".join(f"newmtl m{i}\nmap_Kd {name}.png\n" for i, name in enumerate(names))
+    obj = "mtllib s.mtl\nvn 1 0 0\n" + "".join(f"o O{i}\nv {i} 0 0\nv {i} 1 0\nv {i} 0 1\nusemtl m{i}\nf {3*i+1}//1 {3*i+2}//1 {3*i+3}//1\n" for i in range(len(names)))
+    (tmp_path / "s.mtl").write_text(mtl)
+    (tmp_path / "s.obj").write_text(obj)
+    hs = rt.HostScene(str(tmp_path / "s.obj"))
+    assert len(hs.textures) == len(names)
+    for got, name in zip(hs.textures, names):
+        want = np.array(Image.open(str(tmp_path / f"{name}.png")).convert("RGBA"), np.uint8)
+        assert got.shape == want.shape and np.array_equal(got, want), name
