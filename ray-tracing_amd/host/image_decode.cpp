@@ -1,7 +1,7 @@
 // image_decode.cpp — texture image loading for the host scene loader.
 // ≙ `image::load(file, format)…into_rgba8()` at /root/reference/src/scene.rs:157-170.
 // The reference accepts whatever the `image` crate decodes; this host decodes
-// PNG (8/16-bit, grey / grey+alpha / RGB / RGBA / palette, non-interlaced;
+// PNG (1-16-bit, grey / grey+alpha / RGB / RGBA / palette, tRNS, plain or Adam7-interlaced;
 // inflate by zlib) and binary PPM (P6).  Anything else is reported as an error
 // (the reference panics on a failed decode, src/scene.rs:165-168).
 #include <zlib.h>
@@ -39,59 +39,84 @@ bool decode_png(const std::vector<uint8_t> &f, Image &img, std::string &err) {
         pos += 12 + (size_t)n;
     }
     if (w == 0 || h == 0 || w > 65536 || h > 65536) { err = "bad PNG dimensions"; return false; }
-    if (interlace) { err = "interlaced PNG is not supported"; return false; }
+    if (interlace > 1) { err = "unknown PNG interlace method"; return false; }
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!channels || !(depth == 8 || depth == 16 || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4)) ||
+    if (!channels || !(depth == 8 || (depth == 16 && ctype != 3) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4)) ||
                        (ctype == 0 && (depth == 1 || depth == 2 || depth == 4)))) { err = "unsupported PNG colour type / bit depth"; return false; }
-    const size_t bpp_bits = (size_t)channels * depth, stride = (w * bpp_bits + 7) / 8, bpp = (bpp_bits + 7) / 8;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    const size_t bpp_bits = (size_t)channels * depth, bpp = (bpp_bits + 7) / 8;
+    // Sub-images: the whole picture, or the seven passes of Adam7 (PNG spec 8.2), each filtered on its own
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole = {0, 0, 1, 1};
+    const Pass *passes = interlace ? adam7 : &whole;
+    const int n_passes = interlace ? 7 : 1;
+    size_t total = 0;
+    for (int k = 0; k < n_passes; k++) {
+        const uint32_t pw = (w - passes[k].x0 + passes[k].dx - 1) / passes[k].dx, ph = (h - passes[k].y0 + passes[k].dy - 1) / passes[k].dy;
+        if (passes[k].x0 < w && passes[k].y0 < h && pw && ph) total += ((pw * bpp_bits + 7) / 8 + 1) * (size_t)ph;
+    }
+    std::vector<uint8_t> raw(total);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) { err = "PNG inflate failed"; return false; }
-    // undo the scanline filters in place
-    std::vector<uint8_t> prev(stride, 0);
-    for (uint32_t y = 0; y < h; y++) {
-        uint8_t *row = &raw[(stride + 1) * (size_t)y];
-        const int filter = row[0];
-        uint8_t *cur = row + 1;
-        for (size_t i = 0; i < stride; i++) {
-            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = cur[i];
-            switch (filter) {
-                case 0: break;
-                case 1: x += a; break;
-                case 2: x += b; break;
-                case 3: x += (a + b) >> 1; break;
-                case 4: { int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-                default: err = "bad PNG filter"; return false;
-            }
-            cur[i] = (uint8_t)x;
-        }
-        memcpy(prev.data(), cur, stride);
-    }
     img.width = w; img.height = h;
     img.rgba.assign((size_t)w * h * 4, 255);
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t *cur = &raw[(stride + 1) * (size_t)y + 1];
-        for (uint32_t x = 0; x < w; x++) {
-            uint8_t *o = &img.rgba[4 * ((size_t)y * w + x)];
-            auto sample = [&](int ch) -> uint8_t {   // 8-bit value of channel ch (16-bit: high byte, like into_rgba8's >> 8)
-                if (depth == 8) return cur[(size_t)x * channels + ch];
-                if (depth == 16) return cur[2 * ((size_t)x * channels + ch)];
-                size_t bit = (size_t)x * depth;
-                int v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
-                return (uint8_t)v;
-            };
-            if (ctype == 3) {
-                int idx = sample(0);
-                if ((size_t)idx * 3 + 2 < plte.size()) { o[0] = plte[3 * idx]; o[1] = plte[3 * idx + 1]; o[2] = plte[3 * idx + 2]; }
-                o[3] = (size_t)idx < trns.size() ? trns[idx] : 255;
-            } else if (ctype == 0 || ctype == 4) {
-                int v = sample(0);
-                if (depth < 8) v = v * 255 / ((1 << depth) - 1);
-                o[0] = o[1] = o[2] = (uint8_t)v;
-                if (ctype == 4) o[3] = sample(1);
-            } else {
-                o[0] = sample(0); o[1] = sample(1); o[2] = sample(2);
-                if (ctype == 6) o[3] = sample(3);
+    // 16-bit samples become 8-bit as the `image` crate's into_rgba8() makes them (image 0.25, FromPrimitive<u16> for u8:
+    // round(c * 255 / 65535) = (c + 128) / 257; the crate is not vendored with the reference, so this is its published rule)
+    auto to8 = [](uint32_t c16) -> uint8_t { return (uint8_t)((c16 + 128u) / 257u); };
+    size_t at = 0;
+    for (int k = 0; k < n_passes; k++) {
+        const Pass &ps = passes[k];
+        if (ps.x0 >= w || ps.y0 >= h) continue;
+        const uint32_t pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        const size_t stride = (pw * bpp_bits + 7) / 8;
+        std::vector<uint8_t> prev(stride, 0);
+        for (uint32_t py = 0; py < ph; py++) {
+            uint8_t *row = &raw[at];
+            at += stride + 1;
+            const int filter = row[0];
+            uint8_t *cur = row + 1;
+            for (size_t i = 0; i < stride; i++) {   // undo the scanline filter in place
+                int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = cur[i];
+                switch (filter) {
+                    case 0: break;
+                    case 1: x += a; break;
+                    case 2: x += b; break;
+                    case 3: x += (a + b) >> 1; break;
+                    case 4: { int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+                    default: err = "bad PNG filter"; return false;
+                }
+                cur[i] = (uint8_t)x;
+            }
+            memcpy(prev.data(), cur, stride);
+            const uint32_t y = ps.y0 + py * ps.dy;
+            for (uint32_t px = 0; px < pw; px++) {
+                const uint32_t x = ps.x0 + px * ps.dx;
+                uint8_t *o = &img.rgba[4 * ((size_t)y * w + x)];
+                auto raw_sample = [&](int ch) -> uint32_t {   // the sample as stored: 1..16 bits
+                    if (depth == 8) return cur[(size_t)px * channels + ch];
+                    if (depth == 16) { const uint8_t *q = &cur[2 * ((size_t)px * channels + ch)]; return ((uint32_t)q[0] << 8) | q[1]; }
+                    size_t bit = (size_t)px * depth;
+                    return (uint32_t)(cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+                };
+                auto sample8 = [&](int ch) -> uint8_t { const uint32_t v = raw_sample(ch); return depth == 16 ? to8(v) : (uint8_t)v; };
+                if (ctype == 3) {
+                    const uint32_t idx = raw_sample(0);
+                    if ((size_t)idx * 3 + 2 < plte.size()) { o[0] = plte[3 * idx]; o[1] = plte[3 * idx + 1]; o[2] = plte[3 * idx + 2]; }
+                    else { o[0] = o[1] = o[2] = 0; }
+                    o[3] = (size_t)idx < trns.size() ? trns[idx] : 255;
+                } else if (ctype == 0 || ctype == 4) {
+                    const uint32_t r = raw_sample(0);
+                    uint32_t v = depth == 16 ? to8(r) : r;
+                    if (depth < 8) v = v * 255 / ((1u << depth) - 1u);
+                    o[0] = o[1] = o[2] = (uint8_t)v;
+                    if (ctype == 4) o[3] = sample8(1);
+                    else if (trns.size() >= 2 && r == (((uint32_t)trns[0] << 8) | trns[1])) o[3] = 0;       // tRNS colour key (PNG spec 11.3.2.1)
+                } else {
+                    o[0] = sample8(0); o[1] = sample8(1); o[2] = sample8(2);
+                    if (ctype == 6) o[3] = sample8(3);
+                    else if (trns.size() >= 6 && raw_sample(0) == (((uint32_t)trns[0] << 8) | trns[1]) && raw_sample(1) == (((uint32_t)trns[2] << 8) | trns[3]) &&
+                             raw_sample(2) == (((uint32_t)trns[4] << 8) | trns[5])) o[3] = 0;
+                }
             }
         }
     }

@@ -184,50 +184,59 @@ def test_textured_scene_matches_oracle(rt, oracle_mod, obj_loader, textured_scen
     assert not np.array_equal(plain, want)
 
 
-def _png_bytes(rng, w, h, ctype, depth, pixels, plte=None, trns=None):
-    """A PNG written by hand: every row gets a random filter type (0-4, applied here as the spec defines them), the compressed
-    stream is cut into several IDAT chunks, ancillary chunks are sprinkled in."""
+def _png_bytes(rng, w, h, ctype, depth, pixels, plte=None, trns=None, interlace=0):
+    """A PNG written by hand: plain or Adam7-interlaced, every row of every pass gets a random filter type (0-4, applied here as the
+    spec defines them), the compressed stream is cut into several IDAT chunks, ancillary chunks are sprinkled in."""
     import struct, zlib
     channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
     bits = channels * depth
-    stride, bpp = (w * bits + 7) // 8, max(1, bits // 8)
-    rows = []
-    for y in range(h):
+    bpp = max(1, bits // 8)
+
+    def pack_row(px):                           # px: [n, channels] samples -> bytes, most significant first
         if depth == 8:
-            rows.append(bytes(pixels[y].reshape(-1).astype(np.uint8)))
-        else:                                   # packed samples, most significant first
-            acc, out, nb = 0, bytearray(), 0
-            for v in pixels[y].reshape(-1):
-                acc = (acc << depth) | int(v); nb += depth
-                if nb == 8:
-                    out.append(acc); acc = nb = 0
-            if nb:
-                out.append(acc << (8 - nb))
-            rows.append(bytes(out))
+            return bytes(px.reshape(-1).astype(np.uint8))
+        if depth == 16:
+            return px.reshape(-1).astype(">u2").tobytes()
+        acc, out, nb = 0, bytearray(), 0
+        for v in px.reshape(-1):
+            acc = (acc << depth) | int(v); nb += depth
+            if nb == 8:
+                out.append(acc); acc = nb = 0
+        if nb:
+            out.append(acc << (8 - nb))
+        return bytes(out)
+
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)] if interlace else [(0, 0, 1, 1)]
     raw = bytearray()
-    prev = bytes(stride)
-    for row in rows:
-        ft = int(rng.integers(0, 5))
-        f = bytearray(stride)
-        for i in range(stride):
-            a = row[i - bpp] if i >= bpp else 0
-            b = prev[i]
-            c = prev[i - bpp] if i >= bpp else 0
-            if ft == 0: pred = 0
-            elif ft == 1: pred = a
-            elif ft == 2: pred = b
-            elif ft == 3: pred = (a + b) // 2
-            else:
-                p = a + b - c
-                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
-                pred = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
-            f[i] = (row[i] - pred) & 255
-        raw.append(ft); raw += f
-        prev = row
+    for x0, y0, dx, dy in passes:
+        sub = pixels[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        stride = (sub.shape[1] * bits + 7) // 8
+        prev = bytes(stride)
+        for y in range(sub.shape[0]):
+            row = pack_row(sub[y])
+            ft = int(rng.integers(0, 5))
+            f = bytearray(stride)
+            for i in range(stride):
+                a = row[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 0: pred = 0
+                elif ft == 1: pred = a
+                elif ft == 2: pred = b
+                elif ft == 3: pred = (a + b) // 2
+                else:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+                f[i] = (row[i] - pred) & 255
+            raw.append(ft); raw += f
+            prev = row
     z = zlib.compress(bytes(raw), int(rng.integers(0, 10)))
     def chunk(t, body):
         return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xFFFFFFFF)
-    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
     if rng.random() < 0.5:
         out += chunk(b"gAMA", struct.pack(">I", 45455))
     if plte is not None:
@@ -242,35 +251,74 @@ def _png_bytes(rng, w, h, ctype, depth, pixels, plte=None, trns=None):
     return out + chunk(b"IEND", b"")
 
 
-def test_png_decoder_random_files_against_pil(rt, tmp_path):
-    """Hand-written PNGs of every 8-bit-or-less colour type / depth the decoder takes (grey 1/2/4/8, RGB 8, palette 1/2/4/8 with and
-    without tRNS, grey+alpha 8, RGBA 8), random sizes, a random filter per row, split IDAT: host/image_decode.cpp == PIL."""
+def _expected_rgba(ctype, depth, pixels, plte, key):
+    """What the PNG spec + the `image` crate's into_rgba8() make of the samples: palette look-up, grey replicated, sub-byte grey scaled
+    to 0..255, 16-bit -> 8-bit as round(c * 255 / 65535) = (c + 128) // 257, tRNS as per-index alpha or as a colour key."""
+    h, w = pixels.shape[:2]
+    out = np.full((h, w, 4), 255, np.uint8)
+    to8 = (lambda v: ((v.astype(np.uint32) + 128) // 257)) if depth == 16 else (lambda v: v)
+    if ctype == 3:
+        idx = pixels[..., 0]
+        out[..., :3] = plte[idx]
+        if key is not None:
+            alpha = np.full(len(plte), 255, np.uint8)
+            alpha[:len(key)] = key
+            out[..., 3] = alpha[idx]
+    elif ctype in (0, 4):
+        g = to8(pixels[..., 0])
+        if depth < 8:
+            g = g * 255 // ((1 << depth) - 1)
+        out[..., :3] = g[..., None]
+        if ctype == 4:
+            out[..., 3] = to8(pixels[..., 1])
+        elif key is not None:
+            out[..., 3] = np.where(pixels[..., 0] == key[0], 0, 255)
+    else:
+        out[..., :3] = to8(pixels[..., :3])
+        if ctype == 6:
+            out[..., 3] = to8(pixels[..., 3])
+        elif key is not None:
+            out[..., 3] = np.where((pixels[..., :3] == np.array(key)).all(-1), 0, 255)
+    return out
+
+
+def test_png_decoder_random_files(rt, tmp_path):
+    """Hand-written PNGs of every colour type / depth (grey 1/2/4/8/16, RGB 8/16, palette 1/2/4/8, grey+alpha 8/16, RGBA 8/16), with and
+    without tRNS (per-index alpha, grey / RGB colour keys), plain and Adam7-interlaced, random sizes (1x1 up), a random filter per
+    row, split IDAT: host/image_decode.cpp gives what the spec says (_expected_rgba), and what PIL gives wherever PIL's own
+    conversion to RGBA8 is the same rule (depth <= 8, no colour key)."""
     from PIL import Image
     rng = np.random.default_rng(11)
-    kinds = [(0, 1), (0, 2), (0, 4), (0, 8), (2, 8), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (6, 8)]
-    names = []
-    for i in range(66):
+    kinds = [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)]
+    names, wants = [], []
+    for i in range(150):
         ctype, depth = kinds[i % len(kinds)]
         w, h = int(rng.integers(1, 40)), int(rng.integers(1, 30))
         channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
-        plte = trns = None
+        plte = trns = key = None
         if ctype == 3:
             n_pal = int(rng.integers(1, (1 << depth) + 1))
             plte = rng.integers(0, 256, (n_pal, 3), dtype=np.uint8)
             pixels = rng.integers(0, n_pal, (h, w, 1))
             if rng.random() < 0.5:
-                trns = rng.integers(0, 256, int(rng.integers(1, n_pal + 1)), dtype=np.uint8)
+                key = trns = rng.integers(0, 256, int(rng.integers(1, n_pal + 1)), dtype=np.uint8)
         else:
             pixels = rng.integers(0, 1 << depth, (h, w, channels))
+            if ctype in (0, 2) and rng.random() < 0.4:                      # a colour key that some pixel really has
+                key = [int(v) for v in pixels[int(rng.integers(0, h)), int(rng.integers(0, w))]]
+                trns = np.array(key, ">u2").tobytes()
         name = f"f{i}_{ctype}_{depth}"
-        (tmp_path / f"{name}.png").write_bytes(_png_bytes(rng, w, h, ctype, depth, pixels, plte, trns))
+        (tmp_path / f"{name}.png").write_bytes(_png_bytes(rng, w, h, ctype, depth, pixels, plte, trns, interlace=int(rng.random() < 0.4)))
         names.append(name)
+        wants.append((_expected_rgba(ctype, depth, pixels, plte, key), depth <= 8 and not (ctype in (0, 2) and key is not None)))
     mtl = "".join(f"newmtl m{i}\nmap_Kd {name}.png\n" for i, name in enumerate(names))
     obj = "mtllib s.mtl\nvn 1 0 0\n" + "".join(f"o O{i}\nv {i} 0 0\nv {i} 1 0\nv {i} 0 1\nusemtl m{i}\nf {3*i+1}//1 {3*i+2}//1 {3*i+3}//1\n" for i in range(len(names)))
     (tmp_path / "s.mtl").write_text(mtl)
     (tmp_path / "s.obj").write_text(obj)
     hs = rt.HostScene(str(tmp_path / "s.obj"))
     assert len(hs.textures) == len(names)
-    for got, name in zip(hs.textures, names):
-        want = np.array(Image.open(str(tmp_path / f"{name}.png")).convert("RGBA"), np.uint8)
-        assert got.shape == want.shape and np.array_equal(got, want), name
+    for got, name, (want, ask_pil) in zip(hs.textures, names, wants):
+        assert got.shape == want.shape and np.array_equal(got, want), f"{name}: differs from the spec's result"
+        if ask_pil:                                      # (PIL keys sub-byte grey differently and reduces 16 bits by truncation)
+            pil = np.array(Image.open(str(tmp_path / f"{name}.png")).convert("RGBA"), np.uint8)
+            assert np.array_equal(got, pil), f"{name}: differs from PIL"
