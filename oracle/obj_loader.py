@@ -123,7 +123,8 @@ def strip_flags(path: str) -> str:
 
 
 def _load_image(path: str) -> np.ndarray:
-    """image::load(...).into_rgba8() (src/scene.rs:163-164), via PIL here."""
+    """image::load(...).into_rgba8() (src/scene.rs:163-164), via PIL here.  8-bit-or-less PNGs only: PIL reduces 16-bit samples by
+    truncation, the image crate by rounding ((c + 128) / 257, what host/image_decode.cpp does; tests/test_textures.py checks that rule)."""
     from PIL import Image
     return np.array(Image.open(path).convert("RGBA"), np.uint8)
 
