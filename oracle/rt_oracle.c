@@ -742,10 +742,36 @@ OScene *oracle_scene_create(const OVertex *vertices, uint64_t n_vertices,
             for (int a = 0; a < 3; a++) {
                 boxes[i].lo[a] = fminf(pa[a], fminf(pb[a], pc[a]));
                 boxes[i].hi[a] = fmaxf(pa[a], fmaxf(pb[a], pc[a]));
-                boxes[i].c[a] = 0.5f * boxes[i].lo[a] + 0.5f * boxes[i].hi[a];
             }
             sc->order[i] = (uint32_t)i;
         }
+        /* The BVH mode must find what brute force finds.  Two things break that with exact boxes (both found by
+         * tests/checkers/fuzz_parity.py --big, where brute force sided against this BVH):
+         *  - a ray that grazes a triangle within the rounding of tri_test (which grows with the distance from the ray's origin
+         *    and with 1 / |cos| of the incidence, not with the triangle's size) is accepted by the test while passing beside the
+         *    triangle's exact box: every box is widened by 2^-16 of the scene's largest finite |coordinate|;
+         *  - a primitive with a NaN / infinite corner (never hit, every comparison of its test fails) would make the boxes of
+         *    all its ancestors infinite and their slab arithmetic NaN: it gets an empty (inverted, finite) box. */
+        float scene_abs = 0.0f;
+        for (uint64_t i = 0; i < np; i++) {
+            int finite = 1;
+            for (int a = 0; a < 3; a++)
+                if (!(boxes[i].lo[a] >= -3.0e38f && boxes[i].hi[a] <= 3.0e38f)) finite = 0;
+            if (i < nt) {                 /* min / max skip NaNs: look at the corners themselves */
+                const float *q = &sc->tris[i].a.x;
+                for (int a = 0; a < 9; a++) if (!(q[a] >= -3.0e38f && q[a] <= 3.0e38f)) finite = 0;
+            }
+            for (int a = 0; a < 3; a++) {
+                if (!finite) { boxes[i].lo[a] = 3.0e38f; boxes[i].hi[a] = -3.0e38f; }
+                else scene_abs = fmaxf(scene_abs, fmaxf(fabsf(boxes[i].lo[a]), fabsf(boxes[i].hi[a])));
+            }
+        }
+        const float pad = scene_abs * 1.52587890625e-5f;
+        for (uint64_t i = 0; i < np; i++)
+            for (int a = 0; a < 3; a++) {
+                if (boxes[i].lo[a] <= boxes[i].hi[a]) { boxes[i].lo[a] -= pad; boxes[i].hi[a] += pad; }
+                boxes[i].c[a] = 0.5f * boxes[i].lo[a] + 0.5f * boxes[i].hi[a];
+            }
         sc->nodes = (ONode *)malloc(sizeof(ONode) * (2 * np + 1));
         sc->n_nodes = 1;
         OBuild b = {sc, boxes, 2 * np + 1};

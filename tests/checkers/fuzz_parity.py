@@ -15,6 +15,7 @@ ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-tris", type=int, default=400, help="per geometry")
 ap.add_argument("--node-format", type=int, default=0, help="RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte, 2 32-byte binary nodes, 3 80-byte, 4 64-byte 8-ary nodes")
+ap.add_argument("--big", action="store_true", help="bigger scenes and windows (use --max-tris 50000); the checker is then the oracle's own BVH mode, not brute force")
 ap.add_argument("--only", type=int, default=-1, help="run just this iteration (the random stream is still advanced through the others), with details")
 ap.add_argument("--force-aov", type=int, default=-1)
 ap.add_argument("--force-kernel", type=int, default=-1)
@@ -107,7 +108,7 @@ for it in range(args.iters):
         T[:, 3::4] += ((rng.random((n_geo, 3)) - 0.5) * spread * 60).astype(np.float32); notes.add('far move')
     refit = int(rng.choice([2, 2, 2, 1, 0]))             # RT_OPT_REFIT: device refit, host refit, rebuild
     cw = rng.random() < 0.2                              # RT_OPT_FRONT_FACE_CW
-    w, h = int(rng.integers(1, 70)), int(rng.integers(1, 50))
+    w, h = (int(rng.integers(1, 70)), int(rng.integers(1, 50))) if not args.big else (int(rng.integers(64, 320)), int(rng.integers(48, 200)))
     cam = centre + (rng.random(3) - 0.5) * 3 * spread
     kw = dict(max_bounces=int(rng.integers(0, 6)), samples=int(rng.integers(1, 4)) if rng.random() < 0.97 else 0, fov=float(rng.uniform(0.3, 2.5)),
               flags=int(rng.integers(0, 2)), frame=int(rng.integers(1, 2**32)), exposure=float(rng.choice([1.0, rng.uniform(0.1, 4.0)])),
@@ -139,13 +140,14 @@ for it in range(args.iters):
         continue
     if args.force_kernel >= 0:
         kernel = args.force_kernel
-    osc = oracle.OracleScene(scene, transforms=T, spheres=S, build_bvh=False)
+    osc = oracle.OracleScene(scene, transforms=T, spheres=S, build_bvh=args.big)
+    omode = 1 if args.big else 0
     oracle.lib().oracle_scene_set_front_face_cw(osc.handle, int(cw))
     if n_frames == 1:
-        want, want_hits, cnt = osc.render(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=0, want_hits=True)
+        want, want_hits, cnt = osc.render(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=omode, want_hits=True)
     else:                                                # the cold-start frame sequence of src/app.rs:78-96
         kw.pop("frame")
-        want, cnt = osc.render_frames(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), n_frames, mode=0)
+        want, cnt = osc.render_frames(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), n_frames, mode=omode)
         want_hits = None
     with (rt.Group([0] * shards) if shards > 1 else rt.Context(0)) as ctx:
         ctx.set_option(rt.RT_OPT_NODE_FORMAT, args.node_format)
@@ -186,6 +188,13 @@ for it in range(args.iters):
         print(f"  rays device {st.rays} oracle {cnt.rays}; {int(diff.sum())} of {diff.size} pixels differ; first: {[(int(x), int(y)) for x, y in zip(xs[:8], ys[:8])]}")
         for x, y in list(zip(xs[:4], ys[:4])):
             print(f"   ({x},{y}): device {got[y, x]} oracle {want[y, x]}")
+    if args.only >= 0 and args.big:                      # who is right?  ask brute force (slow)
+        if n_frames == 1:
+            bf, bf_hits, bcnt = osc.render(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=0, want_hits=True)
+        else:
+            bf, bcnt = osc.render_frames(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), n_frames, mode=0)
+        eq = lambda a, b: bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+        print(f"  brute force: rays {bcnt.rays}; device == brute force: {eq(got, bf)}; oracle BVH == brute force: {eq(want, bf)}")
     total_rays += int(cnt.rays)
     total_hits += int(cnt.hits)
     what = f"{len(I) // 3} tris in {n_geo} geometries" + (f" + {len(S)} spheres" if S is not None else "") + (f" + {len(textures)} textures" if textures else "") + \
