@@ -284,3 +284,57 @@ def test_bench_self_launch_relays_failure():
     assert r.returncode != 0
     assert "rank(s) failed" in r.stderr and "needs a GPU" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_app_random_event_sequences(rt):
+    """The frame driver (host/app.cpp) against a line-by-line Python model of App::render / invalidate_accumulation
+    (src/app.rs:41-44,74-96) on random event sequences: frames at random times, invalidations, parameter edits, window
+    resizes, screen_fraction and accumulate changes."""
+    f32 = np.float32
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        W, H = int(rng.integers(1, 3000)), int(rng.integers(1, 2000))
+        t = float(rng.uniform(0, 10))
+        app = rt.App(W, H, now=t)
+        m = dict(inner=[W, H], last_window=[0, 0], last_inv=t, accumulate=1, fraction=2, frame=0, acc=1)       # src/main.rs:63-92
+        for step in range(40):
+            t += float(rng.choice([0.0, rng.uniform(0, 0.3), rng.uniform(0, 3)]))
+            ev = rng.random()
+            if ev < 0.1:
+                app.invalidate(t)
+                m["last_inv"], m["acc"] = t, 0                                        # src/app.rs:41-44
+            elif ev < 0.2:
+                m["fraction"] = int(rng.integers(1, 9))
+                app.state["screen_fraction"] = m["fraction"]
+            elif ev < 0.25:
+                m["accumulate"] ^= 1
+                app.state["accumulate"] = m["accumulate"]
+            elif ev < 0.35:
+                m["inner"] = [int(rng.integers(1, 3000)), int(rng.integers(1, 2000))]
+                app.state["inner_size"][0] = m["inner"]
+            elif ev < 0.45:
+                edited = app.uniform.copy()
+                changed = rng.random() < 0.6
+                if changed:
+                    edited["samples"] = int(edited["samples"][0]) + 1
+                edited["frame"] = 12345                                               # not a hashed field
+                assert app.set_params(edited, t) is changed
+                if changed:
+                    m["last_inv"], m["acc"] = t, 0
+            else:
+                elapsed = min(max(f32(t - m["last_inv"]), f32(0.0)), f32(1.0))
+                dynamic = f32(1.0) + f32(3.0) * (f32(1.0) - elapsed)                  # :75-76
+                m["acc"] += 1                                                         # :78
+                if not m["accumulate"]:
+                    m["acc"] = 0                                                      # :79-81
+                div = max(m["fraction"], int(dynamic))                                # :83-85
+                window = [m["inner"][0] // div, m["inner"][1] // div]
+                resized = window != m["last_window"]
+                if resized:
+                    m["acc"], m["last_window"] = 0, window                            # :87-93
+                m["frame"] += 1                                                       # :96
+                assert app.begin_frame(t) is resized, (trial, step)
+                u = app.uniform[0]
+                assert [int(x) for x in u["window"]] == window, (trial, step)
+                assert int(u["frame"]) == m["frame"] and int(u["accumulation_frame"]) == m["acc"], (trial, step, m)
+                assert float(u["aspect"]) == float(f32(m["inner"][0]) / f32(m["inner"][1]))
