@@ -72,20 +72,41 @@ def cpu_model():
 
 def self_launch(n):
     """`python bench.py --gpus N` typed as is (no torch.distributed.run around it): start N fresh child processes,
-    one rank per GPU, BEFORE this process touches torch.cuda or HIP; wait; relay the children's output (rank 0
-    prints the JSON line); fail if any child fails.  Nothing is exec'ed and nothing is retried."""
+    one rank per GPU, BEFORE this process touches torch.cuda or HIP; wait; relay rank 0's output (it prints the JSON
+    line); fail if any child fails — and if one dies while the others wait for it in a collective, stop those (the
+    exact processes started here) instead of hanging until RCCL's timeout.  Nothing is exec'ed and nothing is retried."""
+    import tempfile
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode("utf-8", "replace"))
+                                      stdout=out0 if r == 0 else None))
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.returncode not in (None, 0) for p in procs):
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:                                   # a rank died: the rest would wait for it in a collective
+        time.sleep(2.0)
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    rcs = [p.returncode for p in procs]
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode("utf-8", "replace"))
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
@@ -106,6 +127,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args.gpus)
 
+    if os.environ.get("RT_BENCH_SELFTEST") == "rank0-waits" and os.environ.get("RANK") == "0":
+        time.sleep(300)      # tests/test_host_side.py: a rank that waits (as in a collective) for one that has died
     import torch
     import torch.distributed as dist
 

@@ -286,6 +286,21 @@ def test_bench_self_launch_relays_failure():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_self_launch_does_not_wait_for_a_dead_rank():
+    """One rank dies while another waits (here: rank 0 sleeps, as it would inside a collective): the parent stops the
+    waiting rank itself and fails within seconds instead of hanging until a collective's timeout."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", RT_BENCH_SELFTEST="rank0-waits")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                       capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "rank(s) failed" in r.stderr
+    assert time.time() - t0 < 60
+
+
 def test_app_random_event_sequences(rt):
     """The frame driver (host/app.cpp) against a line-by-line Python model of App::render / invalidate_accumulation
     (src/app.rs:41-44,74-96) on random event sequences: frames at random times, invalidations, parameter edits, window
