@@ -87,9 +87,12 @@ def self_launch(n):
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else None))
     failed = False
-    while any(p.poll() is None for p in procs):
-        if any(p.returncode not in (None, 0) for p in procs):
+    while True:
+        rcs = [p.poll() for p in procs]          # every rank, every round (poll() is what refreshes returncode)
+        if any(rc not in (None, 0) for rc in rcs):
             failed = True
+            break
+        if all(rc is not None for rc in rcs):
             break
         time.sleep(0.2)
     if failed:                                   # a rank died: the rest would wait for it in a collective
