@@ -759,11 +759,16 @@ int ensure_aov(rt_context *ctx) {
     return RT_OK;
 }
 
+// The work queue's head is a 32-bit counter that every wave bumps ONCE more after the queue has run dry (that is how it learns
+// that it has): the slots of a launch must stay this far below 2^32 or the head would wrap and hand slots out again
+// (8192 resident waves x the largest queue grain, 4096 slots).
+constexpr uint64_t kQueueIndexMax = 0xFFFFFFFFull - (1ull << 26);
+
 // frames a multi-frame launch may take: 32-bit work-queue index, staging budget, 16-bit frame field of the pixel state
 uint32_t frame_group_max(const rt_context *ctx) {
     const uint64_t frame_slots = (uint64_t)((ctx->width + 7u) / 8u) * ctx->local_bands * 64u;
     if (!ctx->opt_pipeline || ctx->opt_kernel != 2 || ctx->opt_aov || ctx->width >= 65536u || frame_slots == 0) return 1;
-    const uint64_t by_queue = 0xFFFFFFFFull / frame_slots;
+    const uint64_t by_queue = kQueueIndexMax / frame_slots;
     const uint64_t by_stage = ctx->stage_budget / (frame_slots * sizeof(float4));
     const uint64_t cap = by_queue < by_stage ? by_queue : by_stage;
     return cap < 1 ? 1u : (uint32_t)(cap < 65535u ? cap : 65535u);
@@ -910,6 +915,8 @@ int check_dispatch(rt_context *ctx, const RtUniform *u) {
                     u->window[0], u->window[1], ctx->width, ctx->height);
     if ((uint64_t)u->window[0] * u->window[1] > 0xFFFFFFFFull)
         return fail(RT_ERR_INVALID_ARGUMENT, "window has more than 2^32 pixels");
+    if ((uint64_t)((u->window[0] + 7u) / 8u) * ctx->local_bands * 64u > kQueueIndexMax)       // pixel slots of one frame (whole 8x8 tiles)
+        return fail(RT_ERR_INVALID_ARGUMENT, "window has more pixel slots than the 32-bit work queue of a launch can index");
     if ((uint64_t)ctx->stack_entries * 256u * 4u + RT_LDS_MATERIALS * 64u + 2048u > 160u * 1024u)      // traversal stacks + the material copy + the 8-ary nodes' child-order table
         return fail(RT_ERR_INVALID_ARGUMENT, "BVH depth %u needs more LDS than a CU has", ctx->stack_entries);
     RT_HIP(hipSetDevice(ctx->device));
@@ -1061,7 +1068,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
                 if (key == 103) ctx->persistent_blocks = 0;     // grid size is recomputed at the next launch
                 return RT_OK;
             }
-            if (key == 108 && value >= 0 && value <= 65536) { ctx->chunk = (uint32_t)value; return RT_OK; }
+            if (key == 108 && value >= 0 && value <= 4096) { ctx->chunk = (uint32_t)value; return RT_OK; }
             if (key == 111 && value >= 0 && value <= 48) { ctx->bvh_max_depth = (uint32_t)value; return RT_OK; }
             if (key == 110 && value >= 0) { ctx->sah_traversal_cost = (float)value / 16.0f; return RT_OK; }
             if (key == 109 && value >= 1) { ctx->stage_budget = (uint64_t)value << 10; return RT_OK; }   // KiB
@@ -1294,7 +1301,7 @@ int rt_dispatch_frames_static(rt_context *ctx, RtUniform *uniform, uint32_t n_fr
             return fail(RT_ERR_INVALID_ARGUMENT, "rt_dispatch_frames_static: %u frames of this window need %llu bytes of staging, the static "
                         "scratch holds %llu (use rt_dispatch_frames, or fewer frames per call)", n_frames, (unsigned long long)need,
                         (unsigned long long)RT_STATIC_STAGE_BYTES);
-        if (frame_slots * n_frames > 0xFFFFFFFFull || n_frames > 65535u)
+        if (frame_slots * n_frames > kQueueIndexMax || n_frames > 65535u)
             return fail(RT_ERR_INVALID_ARGUMENT, "rt_dispatch_frames_static: %u frames exceed the 32-bit work queue of one launch", n_frames);
     }
     RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
