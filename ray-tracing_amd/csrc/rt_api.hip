@@ -761,7 +761,7 @@ int ensure_aov(rt_context *ctx) {
 
 // The work queue's head is a 32-bit counter that every wave bumps ONCE more after the queue has run dry (that is how it learns
 // that it has): the slots of a launch must stay this far below 2^32 or the head would wrap and hand slots out again
-// (8192 resident waves x the largest queue grain, 4096 slots).
+// (8192 resident waves x four times the largest queue grain, 1024 slots).
 constexpr uint64_t kQueueIndexMax = 0xFFFFFFFFull - (1ull << 26);
 
 // frames a multi-frame launch may take: 32-bit work-queue index, staging budget, 16-bit frame field of the pixel state
@@ -1063,12 +1063,15 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             // developer knobs (tools/ab_bench.py, tools/shard_scaling.py): 100..107 scheduler weights (103: resident workgroups per CU, 0 = all that fit) and builder leaf size /
             // bins, 108 queue grain, 109 staging budget in KiB, 110 SAH traversal cost x16, 111 BVH depth cap
             if (key == 106 && (value < 0 || value > 7)) return fail(RT_ERR_INVALID_ARGUMENT, "option 106 (triangles per leaf): 0..7");
+            // a phase weight of 0 would let the scheduler pick a phase nobody waits in, for ever
+            if ((key == 100 || key == 101 || key == 102 || key == 104) && (value < 1 || value > 65536))
+                return fail(RT_ERR_INVALID_ARGUMENT, "option %d (scheduler weight): 1..65536", key);
             if (key >= 100 && key < 108) {
                 ctx->tune[key - 100] = (int32_t)value;
                 if (key == 103) ctx->persistent_blocks = 0;     // grid size is recomputed at the next launch
                 return RT_OK;
             }
-            if (key == 108 && value >= 0 && value <= 4096) { ctx->chunk = (uint32_t)value; return RT_OK; }
+            if (key == 108 && value >= 0 && value <= 1024) { ctx->chunk = (uint32_t)value; return RT_OK; }
             if (key == 111 && value >= 0 && value <= 48) { ctx->bvh_max_depth = (uint32_t)value; return RT_OK; }
             if (key == 110 && value >= 0) { ctx->sah_traversal_cost = (float)value / 16.0f; return RT_OK; }
             if (key == 109 && value >= 1) { ctx->stage_budget = (uint64_t)value << 10; return RT_OK; }   // KiB
