@@ -147,7 +147,7 @@ for session in range(args.sessions):
                 cam = draw_camera(sc)
                 log.append("camera")
             elif op == "option":
-                k = str(rng.choice(["kernel", "aov", "count", "pipeline", "format", "refit"]))
+                k = str(rng.choice(["kernel", "aov", "count", "pipeline", "format", "refit", "stage", "reserve"]))
                 if k == "kernel":
                     opt["kernel"] = int(rng.integers(0, 3)); ctx.set_option(rt.RT_OPT_KERNEL, opt["kernel"])
                 elif k == "aov":
@@ -156,6 +156,11 @@ for session in range(args.sessions):
                     opt["count"] ^= 1; ctx.set_option(rt.RT_OPT_COUNT_TRAVERSAL, opt["count"])
                 elif k == "pipeline":
                     opt["pipeline"] ^= 1; ctx.set_option(rt.RT_OPT_FRAME_PIPELINE, opt["pipeline"])
+                elif k == "stage":                      # developer knob 109: staging budget in KiB -> runs of frames split into several launches
+                    ctx.set_option(109, int(rng.choice([1, 4, 16, 64, 4 << 20])))
+                elif k == "reserve":
+                    if shards == 1 and w:
+                        ctx.frames_reserve(int(rng.integers(1, 6)))
                 elif k == "format":
                     ctx.set_option(rt.RT_OPT_NODE_FORMAT, int(rng.integers(0, 5)))      # takes effect at the next upload / rebuild
                 else:
@@ -173,7 +178,7 @@ for session in range(args.sessions):
                     fresh = False
                     log.append(f"dispatch(frame {frame}, accumulation_frame {acc})")
                 else:
-                    n = int(rng.integers(1, 4))
+                    n = int(rng.integers(1, 6))
                     static = shards == 1 and not opt["aov"] and rng.random() < 0.4
                     u = uniform(rt, w, h, cam, frame_ctr, acc_ctr)
                     (ctx.dispatch_frames_static if static else ctx.dispatch_frames)(u, n)
