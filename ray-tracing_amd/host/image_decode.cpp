@@ -55,6 +55,8 @@ bool decode_png(const std::vector<uint8_t> &f, Image &img, std::string &err) {
         const uint32_t pw = (w - passes[k].x0 + passes[k].dx - 1) / passes[k].dx, ph = (h - passes[k].y0 + passes[k].dy - 1) / passes[k].dy;
         if (passes[k].x0 < w && passes[k].y0 < h && pw && ph) total += ((pw * bpp_bits + 7) / 8 + 1) * (size_t)ph;
     }
+    // deflate cannot expand more than ~1032:1: a header that promises more than the IDAT bytes can hold is refused before anything is allocated
+    if (total > idat.size() * 1040 + 1024) { err = "PNG inflate failed"; return false; }
     std::vector<uint8_t> raw(total);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) { err = "PNG inflate failed"; return false; }

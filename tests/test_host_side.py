@@ -264,7 +264,43 @@ def test_host_half_under_sanitizers(tmp_path):
     b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     if b.returncode != 0:
         pytest.skip("sanitizer build unavailable: " + b.stderr[-300:])
-    r = subprocess.run([exe] + [scene_path(n) for n in ("cornell-box", "teapot", "teapot-circle")], capture_output=True, text=True, timeout=300,
+    # damaged inputs: PNGs with flipped bytes, cut short or with absurd headers, OBJ text with lines cut and tokens garbled
+    from test_textures import _png_bytes
+    rng = np.random.default_rng(3)
+    extra = []
+    for i in range(40):
+        ctype, depth = [(0, 1), (0, 8), (0, 16), (2, 8), (3, 2), (3, 8), (4, 8), (6, 8), (6, 16)][i % 9]
+        w, h = int(rng.integers(1, 24)), int(rng.integers(1, 24))
+        ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+        plte = rng.integers(0, 256, (1 << min(depth, 4), 3), dtype=np.uint8) if ctype == 3 else None
+        px = rng.integers(0, len(plte) if ctype == 3 else 1 << depth, (h, w, ch))
+        good = _png_bytes(rng, w, h, ctype, depth, px, plte, None, interlace=int(rng.random() < 0.5))
+        for k in range(8):
+            data = bytearray(good)
+            kind = k % 4
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 6))):
+                    data[int(rng.integers(8, len(data)))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                data = data[:int(rng.integers(8, len(data)))]
+            elif kind == 2:
+                data[16:24] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))          # width / height
+            else:
+                data[24:26] = bytes(rng.integers(0, 17, 2, dtype=np.uint8))           # depth / colour type
+            path = tmp_path / f"d{i}_{k}.png"
+            path.write_bytes(bytes(data))
+            extra.append(str(path))
+    obj_lines = open(scene_path("cornell-box")).read().splitlines()
+    for i in range(30):
+        lines = list(obj_lines[:400])
+        for _ in range(int(rng.integers(1, 12))):
+            j = int(rng.integers(0, len(lines)))
+            kind = int(rng.integers(0, 4))
+            lines[j] = [lines[j][:len(lines[j]) // 2], lines[j] + " 1e999 nan -", "f 1/2/3 -99999//7 0 5//", lines[j].replace(" ", "/")][kind]
+        path = tmp_path / f"o{i}.bad"
+        path.write_text("\n".join(lines))
+        extra.append(str(path))
+    r = subprocess.run([exe] + [scene_path(n) for n in ("cornell-box", "teapot", "teapot-circle")] + extra, capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:verify_asan_link_order=0"))
     if "ASan runtime does not come first" in r.stderr:
         pytest.skip("a preloaded library precedes the ASan runtime here")

@@ -15,6 +15,18 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; i++) {
         rt_host::Scene sc;
         std::string err;
+        const size_t len = strlen(argv[i]);
+        if (len > 4 && (!strcmp(argv[i] + len - 4, ".png") || !strcmp(argv[i] + len - 4, ".ppm"))) {
+            // an image file, possibly damaged on purpose: decoding may fail, it must not fault or over-allocate
+            rt_host::Image img;
+            const bool ok = rt_host::load_image_rgba8(argv[i], img, err);
+            if (ok && img.rgba.size() != (size_t)img.width * img.height * 4) { printf("%s: size mismatch\n", argv[i]); bad++; }
+            continue;
+        }
+        if (len > 4 && !strcmp(argv[i] + len - 4, ".bad")) {       // an OBJ file damaged on purpose: may be refused, must not fault
+            (void)rt_host::load_obj(argv[i], sc, err);
+            continue;
+        }
         if (!rt_host::load_obj(argv[i], sc, err)) { printf("%s: %s\n", argv[i], err.c_str()); bad++; continue; }
         std::vector<float> corners;
         std::vector<uint32_t> ids;
