@@ -218,7 +218,10 @@ int rt_set_option(rt_context *ctx, int key, int64_t value);
  * the Vulkan driver does for the reference at src/scene.rs:56-64).
  * `transforms` = n_primitives row-major 3x4 matrices, or NULL for identity
  * (src/scene.rs:53-54).  A triangle or sphere with a NaN / infinite corner, centre or radius (after its transform) is accepted and is
- * never hit — what the arithmetic contract's tests give for it — and does not disturb the rest of the scene. */
+ * never hit — what the arithmetic contract's tests give for it — and does not disturb the rest of the scene.
+ * Arrays are validated before anything is built (ranges inside their buffers, index counts multiples of 3, a model per geometry);
+ * a refused upload leaves the context WITHOUT a scene (RT_ERR_NO_SCENE on dispatch), while a refused rt_spheres_upload or
+ * rt_models_update leaves the scene that was in force untouched. */
 int rt_scene_upload(rt_context *ctx,
                     const RtVertex *vertices, uint64_t n_vertices,
                     const uint32_t *indices, uint64_t n_indices,

@@ -1103,8 +1103,11 @@ int rt_scene_upload(rt_context *ctx, const RtVertex *vertices, uint64_t n_vertic
 int rt_spheres_upload(rt_context *ctx, const RtSphere *spheres, uint64_t n_spheres) {
     if (!ctx || (n_spheres && !spheres)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_spheres_upload before rt_scene_upload");
-    ctx->hs->spheres.assign(spheres, spheres + n_spheres);
-    return build_and_upload(ctx);
+    std::vector<RtSphere> old(spheres, spheres + n_spheres);
+    old.swap(ctx->hs->spheres);
+    const int r = build_and_upload(ctx);
+    if (r != RT_OK && !ctx->models_committed) old.swap(ctx->hs->spheres);    // refused before anything reached the device: the old spheres stay in force
+    return r;
 }
 
 int rt_textures_upload(rt_context *ctx, const RtTexture *textures, uint32_t n_textures) {
@@ -1597,9 +1600,11 @@ int rt_group_scene_upload(rt_group *g, const RtVertex *vertices, uint64_t n_vert
 int rt_group_spheres_upload(rt_group *g, const RtSphere *spheres, uint64_t n_spheres) {
     if (!g || (n_spheres && !spheres)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (!g->ctx[0]->have_scene) return fail(RT_ERR_NO_SCENE, "rt_group_spheres_upload before rt_group_scene_upload");
-    g->ctx[0]->hs->spheres.assign(spheres, spheres + n_spheres);
+    std::vector<RtSphere> old(spheres, spheres + n_spheres);
+    old.swap(g->ctx[0]->hs->spheres);
     Built b;
     int r = host_build(g->ctx[0], false, b);
+    if (r != RT_OK) { old.swap(g->ctx[0]->hs->spheres); return r; }          // refused by the host half: the old spheres stay in force
     for (size_t i = 0; i < g->ctx.size() && r == RT_OK; i++) r = device_upload(g->ctx[i], b);
     return r;
 }

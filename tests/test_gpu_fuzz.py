@@ -92,3 +92,70 @@ def test_fuzz_sessions_against_brute_force(node_format):
     tail = "\n".join(r.stdout.splitlines()[-5:])
     assert r.returncode == 0, f"{tail}\n{r.stderr[-2000:]}"
     assert "all identical" in r.stdout.splitlines()[-1], tail
+
+
+def test_corrupted_scene_arrays_are_refused_and_leave_the_context_usable(rt, obj_loader):
+    """One defect per upload — index / vertex / model ranges beyond their buffers, an index count that is no multiple of 3, a
+    transform offset, sphere model or radius out of range, too few models: every one is refused with an error (nothing reaches a
+    kernel), rt_models_update keeps the scene in force when it refuses, and the context renders the intact scene as before."""
+    rng = np.random.default_rng(21)
+    n_geo, n = 3, 40
+    V = np.zeros(3 * n * n_geo, obj_loader.VERTEX_DTYPE)
+    V["position"] = (rng.random((len(V), 3)) * 4 - 2).astype(np.float32)
+    V["normal"] = (0, 1, 0)
+    I = np.tile(np.arange(3 * n, dtype=np.uint32), n_geo)
+    P = np.zeros(n_geo, obj_loader.PRIMITIVE_DTYPE)
+    M = np.zeros(n_geo, obj_loader.MODEL_DTYPE)
+    for g in range(n_geo):
+        P[g] = (3 * n * g, 3 * n, 3 * n * g, 3 * n, g)
+        M[g]["diffuse_color"] = rng.random(3)
+        M[g]["vertex_start"], M[g]["index_start"] = 3 * n * g, 3 * n * g
+    S = np.zeros(4, obj_loader.SPHERE_DTYPE)
+    S["center"] = (rng.random((4, 3)) * 2 - 1).astype(np.float32)
+    S["radius"] = 0.3
+    T = np.tile(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0.5], np.float32), (n_geo, 1))
+    u = rt.make_uniform(32, 24, (0.0, 0.0, -6.0), np.pi / 2, 0.0, max_bounces=2, samples=2)
+
+    def render(ctx):
+        ctx.accum_resize(32, 24)
+        ctx.dispatch(u)
+        return ctx.accum_download().tobytes()
+
+    with rt.Context(0) as ctx:
+        ctx.scene_upload(V, I, P, M, transforms=T)
+        ctx.spheres_upload(S)
+        want = render(ctx)
+        refused = 0
+        for case in range(60):
+            V2, I2, P2, M2, S2, T2 = V.copy(), I.copy(), P.copy(), M.copy(), S.copy(), T.copy()
+            g = int(rng.integers(0, n_geo))
+            kind = case % 10
+            via_update = False
+            if kind == 0: I2[int(rng.integers(0, len(I2)))] = 3 * n + int(rng.integers(0, 1000))
+            elif kind == 1: P2[g]["index_count"] = len(I2) + 3
+            elif kind == 2: P2[g]["first_vertex"] = len(V2) - 5
+            elif kind == 3: P2[g]["index_count"] = 3 * n - 1
+            elif kind == 4: P2[g]["transformation_offset"] = n_geo + int(rng.integers(0, 5))
+            elif kind == 5: M2 = M2[:n_geo - 1]
+            elif kind == 6: M2[g]["vertex_start"] = len(V2)
+            elif kind == 7: S2[1]["model"] = n_geo + 3
+            elif kind == 8: S2[2]["radius"] = float(rng.choice([0.0, -1.0, np.nan]))
+            else:
+                via_update = True
+                M2[g]["index_start"] = len(I2) - 2
+            with pytest.raises(rt.RtError):
+                if via_update:
+                    ctx.models_update(M2, transforms=T2)
+                elif kind in (7, 8):
+                    ctx.spheres_upload(S2)
+                else:
+                    ctx.scene_upload(V2, I2, P2, M2, transforms=T2)
+            refused += 1
+            if via_update or kind in (7, 8):
+                ctx.models_update(M, transforms=T)               # the host copy is intact too: an update of the scene in force goes through
+                assert render(ctx) == want, f"case {case}: the scene in force changed after a refused call"
+            else:
+                ctx.scene_upload(V, I, P, M, transforms=T)
+                ctx.spheres_upload(S)
+                assert render(ctx) == want, f"case {case}"
+        assert refused == 60
