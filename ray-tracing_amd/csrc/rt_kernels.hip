@@ -863,6 +863,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
     int pick = schedule();
     while (pick != PH_DONE) {
         if (pick == PH_NODE) {
+            if (P.phase_prio) __builtin_amdgcn_s_setprio(2);
             do {
                 const int node_lanes = __popcll(__ballot(phase == PH_NODE));
 #pragma unroll
@@ -977,7 +978,9 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                 }
                 pick = schedule();
             } while (pick == PH_NODE);
+            if (P.phase_prio) __builtin_amdgcn_s_setprio(0);
         } else if (pick == PH_LEAF) {
+            if (P.phase_prio) __builtin_amdgcn_s_setprio(1);
             do {
 #pragma unroll
                 for (int rep = 0; rep < RT_LEAF_REPS; rep++) {
@@ -1018,6 +1021,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                 }
                 pick = schedule();
             } while (pick == PH_LEAF);
+            if (P.phase_prio) __builtin_amdgcn_s_setprio(0);
         } else if (pick == PH_SHADE) {
             // hit or miss shading (main.wgsl:46-69); a path that ends starts the pixel's next sample or moves on to FETCH
             do {
