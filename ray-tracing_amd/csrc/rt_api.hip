@@ -160,7 +160,6 @@ struct rt_context {
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
     float sah_traversal_cost = 1.0f; // key 110, in 1/16
     uint32_t bvh_max_depth = 0;      // key 111, 0 = builder default
-    int opt_phase_prio = 0;          // key 112: 0 = by scene size, 1 = off, 2 = on
     uint64_t stage_budget = 4ull << 30;   // bytes of staging a multi-frame launch may use (key 109, tests)
     uint32_t chunk = 0;              // queue grain in pixel slots; 0 = by the amount of work (see launch())
     bool timed = false;
@@ -763,9 +762,6 @@ int ensure_aov(rt_context *ctx) {
 // The work queue's head is a 32-bit counter that every wave bumps ONCE more after the queue has run dry (that is how it learns
 // that it has): the slots of a launch must stay this far below 2^32 or the head would wrap and hand slots out again
 // (8192 resident waves x four times the largest queue grain, 1024 slots).
-#ifndef RT_PRIO_MAX_RECORD_BYTES
-#define RT_PRIO_MAX_RECORD_BYTES (256ull << 20)
-#endif
 constexpr uint64_t kQueueIndexMax = 0xFFFFFFFFull - (1ull << 26);
 
 // frames a multi-frame launch may take: 32-bit work-queue index, staging budget, 16-bit frame field of the pixel state
@@ -851,17 +847,6 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
     P.n_node_chunks = (uint32_t)(ctx->node_bytes / 16u);
     P.wide_stride = ctx->node_stride;
     P.n_slots = ctx->n_tris;
-    {
-        // Wave priority by phase (s_setprio 2 in node steps, 1 in leaf steps, 0 in shading): where the records are cache-resident the
-        // fetch-issuing phases win the issue arbitration against other waves' long shading steps and the L1 path stays fed —
-        // C3 15.95 -> 15.25 ms per step, C2 3.49 -> 3.23; where every node step is a round trip to L2 / HBM it only delays the
-        // shading that starts the next rays: C4 100.4 -> 105 ms.  Hence by the size of the scene's records, unless knob 112 says otherwise.
-        const uint64_t record_bytes = ctx->node_bytes + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));
-        // (tools/prio_threshold.py, lattice scenes at 1080p: binary nodes -5 % at 18 MiB of records, -1..-2 % up to 218 MiB, +2 % at 909 MiB;
-        // 8-ary nodes -5 % at 17 MiB, +4..+6 % from 104 MiB on)
-        const uint64_t limit = ctx->node_wide ? RT_PRIO_MAX_RECORD_BYTES / 4u : RT_PRIO_MAX_RECORD_BYTES;
-        P.phase_prio = ctx->opt_phase_prio == 2 || (ctx->opt_phase_prio == 0 && record_bytes <= limit) ? 1u : 0u;
-    }
     P.queue = static_scratch ? reinterpret_cast<DevQueue *>(static_scratch) : ctx->d_queue;
     memcpy(P.tune, ctx->tune, sizeof P.tune);
     // queue grain: 64 slots (one 8x8 tile) keeps the end of a launch short, which is what counts for a shard of
@@ -1076,7 +1061,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             return RT_OK;
         default:
             // developer knobs (tools/ab_bench.py, tools/shard_scaling.py): 100..107 scheduler weights (103: resident workgroups per CU, 0 = all that fit) and builder leaf size /
-            // bins, 108 queue grain, 109 staging budget in KiB, 110 SAH traversal cost x16, 111 BVH depth cap, 112 wave priority by phase (0 by size, 1 off, 2 on)
+            // bins, 108 queue grain, 109 staging budget in KiB, 110 SAH traversal cost x16, 111 BVH depth cap
             if (key == 106 && (value < 0 || value > 7)) return fail(RT_ERR_INVALID_ARGUMENT, "option 106 (triangles per leaf): 0..7");
             // a phase weight of 0 would let the scheduler pick a phase nobody waits in, for ever
             if ((key == 100 || key == 101 || key == 102 || key == 104) && (value < 1 || value > 65536))
@@ -1088,7 +1073,6 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             }
             if (key == 108 && value >= 0 && value <= 1024) { ctx->chunk = (uint32_t)value; return RT_OK; }
             if (key == 111 && value >= 0 && value <= 48) { ctx->bvh_max_depth = (uint32_t)value; return RT_OK; }
-            if (key == 112 && value >= 0 && value <= 2) { ctx->opt_phase_prio = (int)value; return RT_OK; }
             if (key == 110 && value >= 0) { ctx->sah_traversal_cost = (float)value / 16.0f; return RT_OK; }
             if (key == 109 && value >= 1) { ctx->stage_budget = (uint64_t)value << 10; return RT_OK; }   // KiB
             return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);

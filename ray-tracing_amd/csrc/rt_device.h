@@ -190,8 +190,6 @@ struct RenderParams {
     uint32_t n_node_chunks;              // 16-byte chunks in the node array
     uint32_t wide_stride;                // 8-ary nodes: 16-byte chunks from one node to the next (5 = packed, 8 = one node per 128-byte line)
     uint64_t n_slots;                    // triangle / sphere records
-    uint32_t phase_prio;                 // phased kernel: raise the wave's issue priority while it runs node / leaf steps (rt_api.hip launch())
-    uint32_t pad_prio;
     int32_t tune[8];                     // scheduler weights: [0] NODE, [1] LEAF, [2] SHADE, [4] FETCH (others unused by the kernel)
 #ifdef RT_TAIL_PROBE
     // developer build (make EXTRA=-DRT_TAIL_PROBE): per wave {start, first empty claim, exit} in 100 MHz ticks,

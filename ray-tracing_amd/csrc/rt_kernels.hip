@@ -771,6 +771,20 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 // LEAF (has triangles to test), SHADE (trace finished) — and each loop iteration
 // the wave runs ONE phase body, the one most lanes are waiting for (ballot counts).
 // Lanes in other phases sit that iteration out; nobody waits for a whole ray.
+// Wave priority by phase (s_setprio): a level for node steps, one for leaf steps, 0 otherwise (shading, fetch).
+// Binary nodes (what cache-resident scenes get): node steps 2, leaf steps 1 — the fetch-issuing phases win the issue arbitration
+// against other waves' long shading steps and the L1 path stays fed: C3 15.95 -> 15.25 ms per step, C2 3.49 -> 3.23 (levels 1..3
+// all within 0.5 %; raising SHADE instead: 16.65; lattice scenes: -5 % at 18 MiB of records, -1..-2 % up to 218 MiB, +2 % at 909 MiB).
+// 8-ary nodes (what the library picks once the nodes leave the caches): raising the NODE steps — 208 instructions behind a round
+// trip to L2 / HBM — only delays the shading that starts the next rays (C4 100.4 -> 105 ms, lattice scenes +4..+6 % from 100 MiB of
+// records on); raising the LEAF steps alone (three fetches, 60 instructions) is worth 2 % (C4 100.9 -> 98.5, C5q 57.7 -> 56.3).
+// The rule is by FORMAT and so costs no branch (a run-time flag cost 1.2 % on C3).
+#ifndef RT_PRIO_NODE_BINARY
+#define RT_PRIO_NODE_BINARY 2
+#define RT_PRIO_LEAF_BINARY 1
+#define RT_PRIO_NODE_WIDE 0
+#define RT_PRIO_LEAF_WIDE 2
+#endif
 enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_FETCH = 4, PH_DONE = 5 };
 constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel-frame that has not started its first path
 
@@ -778,6 +792,7 @@ constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel
 template <bool COUNT, bool AOV, bool SPH, bool LDSM, int FMT>
 __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
     constexpr bool Q8 = FMT == 1, WIDE = FMT >= 2, COMPACT = FMT == 3;
+    constexpr int kPrioNode = WIDE ? RT_PRIO_NODE_WIDE : RT_PRIO_NODE_BINARY, kPrioLeaf = WIDE ? RT_PRIO_LEAF_WIDE : RT_PRIO_LEAF_BINARY;
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
     if (WIDE) fill_next_slot_table();
@@ -863,7 +878,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
     int pick = schedule();
     while (pick != PH_DONE) {
         if (pick == PH_NODE) {
-            if (P.phase_prio) __builtin_amdgcn_s_setprio(2);
+            if constexpr (kPrioNode != 0) __builtin_amdgcn_s_setprio(kPrioNode);
             do {
                 const int node_lanes = __popcll(__ballot(phase == PH_NODE));
 #pragma unroll
@@ -978,9 +993,9 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                 }
                 pick = schedule();
             } while (pick == PH_NODE);
-            if (P.phase_prio) __builtin_amdgcn_s_setprio(0);
+            if constexpr (kPrioNode != 0) __builtin_amdgcn_s_setprio(0);
         } else if (pick == PH_LEAF) {
-            if (P.phase_prio) __builtin_amdgcn_s_setprio(1);
+            if constexpr (kPrioLeaf != 0) __builtin_amdgcn_s_setprio(kPrioLeaf);
             do {
 #pragma unroll
                 for (int rep = 0; rep < RT_LEAF_REPS; rep++) {
@@ -1021,7 +1036,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                 }
                 pick = schedule();
             } while (pick == PH_LEAF);
-            if (P.phase_prio) __builtin_amdgcn_s_setprio(0);
+            if constexpr (kPrioLeaf != 0) __builtin_amdgcn_s_setprio(0);
         } else if (pick == PH_SHADE) {
             // hit or miss shading (main.wgsl:46-69); a path that ends starts the pixel's next sample or moves on to FETCH
             do {
