@@ -8,9 +8,9 @@ mkdir -p ../tools/sens
 for v in "base:" "nv12:-DRT_EXP_NODE_VALU=12" "nv24:-DRT_EXP_NODE_VALU=24" "nv48:-DRT_EXP_NODE_VALU=48" "nl1:-DRT_EXP_NODE_LOAD=1" "sv80:-DRT_EXP_SHADE_VALU=80" "sv160:-DRT_EXP_SHADE_VALU=160"; do
   name=${v%%:*}; flag=${v#*:}
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function --offload-arch=gfx950 \
-    -fhip-fp32-correctly-rounded-divide-sqrt -Xarch_host -mfma $flag -fno-slp-vectorize -mllvm -structurizecfg-skip-uniform-regions=1 \
+    -fhip-fp32-correctly-rounded-divide-sqrt -Xarch_host -mfma $flag -DRT_TU_PHASED -fno-slp-vectorize -mllvm -structurizecfg-skip-uniform-regions=1 \
     -c csrc/rt_kernels.hip -o ../tools/sens/k_$name.o || exit 1
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../tools/sens/librt_$name.so ../tools/sens/k_$name.o build/rt_refit.o build/rt_capture.o build/rt_api.o \
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../tools/sens/librt_$name.so ../tools/sens/k_$name.o build/rt_kernels_simple.o build/rt_refit.o build/rt_capture.o build/rt_api.o \
     build/scene_loader.o build/bvh_builder.o build/capture.o build/app.o build/image_decode.o build/host_api.o -lpthread -lz || exit 1
 done
 rm -f ../tools/sens/*.o
