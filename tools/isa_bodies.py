@@ -6,9 +6,9 @@ src = open(os.path.join(ROOT, "ray-tracing_amd/csrc/rt_kernels.hip")).read()
 def mark(s, needle, name, after=True):
     assert needle in s, needle
     return s.replace(needle, (needle + f'\n asm volatile("; MARK {name}");') if after else (f' asm volatile("; MARK {name}");\n' + needle), 1)
-src = mark(src, "        if (pick == PH_NODE) {\n            do {", "node_begin")
+src = mark(src, "        if (pick == PH_NODE) {\n            if constexpr (kPrioNode != 0) __builtin_amdgcn_s_setprio(kPrioNode);\n            do {", "node_begin")
 src = mark(src, "            } while (pick == PH_NODE);", "node_end")
-src = mark(src, "        } else if (pick == PH_LEAF) {\n            do {", "leaf_begin")
+src = mark(src, "        } else if (pick == PH_LEAF) {\n            if constexpr (kPrioLeaf != 0) __builtin_amdgcn_s_setprio(kPrioLeaf);\n            do {", "leaf_begin")
 src = mark(src, "            } while (pick == PH_LEAF);", "leaf_end")
 src = mark(src, "        } else if (pick == PH_SHADE) {", "shade_begin")
 src = mark(src, "            // pixel boundary: write out finished", "shade_end", after=False)
