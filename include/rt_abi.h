@@ -196,7 +196,7 @@ typedef struct RtStats {
                                       4 = 64-byte 8-ary nodes (the same tree; the corner is three 14-bit cells of a per-scene grid:
                                           four fetches and one 64-byte line per visit);
                                       0 (default) = by size: 48-byte binary nodes while the nodes stay in the caches, 64-byte 8-ary
-                                          nodes once they would exceed ~16 MB.  Formats 2-4 need a scene extent <= 2^18 (else 1 is used). */
+                                          nodes once they would exceed ~12 MiB.  Formats 2-4 need a scene extent <= 2^18 (else 1 is used). */
 
 typedef struct rt_context rt_context;
 

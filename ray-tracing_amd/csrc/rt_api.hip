@@ -611,10 +611,12 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     }
     const bool fits = scene_finite && rt_q8_fits(scene_box.lo, scene_box.hi);
     // Format by size (RT_OPT_NODE_FORMAT = 0): scenes whose nodes stay in the caches keep 48-byte binary nodes (fewest VALU
-    // instructions per box; C3: 16.0 vs 18.0 ms per step); past ~16 MB of nodes the fetches miss and the 8-ary nodes win
+    // instructions per box; C3: 16.0 vs 18.0 ms per step); past ~12 MiB of nodes the fetches miss and the 8-ary nodes win
     // (five fetches for eight boxes, 30 visits per ray instead of 67 on C4: 100.6 vs 110.2 ms per step with 32-byte binary nodes).
     // A BVH2 over n primitives with leaves of ~2 has ~n inner nodes of 48 bytes.
-    const bool big = n_prims * sizeof(DevNode) / 2 >= (16ull << 20);
+    // (tools/format_threshold.py, lattice scenes at 1080p, 8-ary against binary nodes: +4 % at 95 k primitives, +1 % at 429 k, -2.7 % at 572 k,
+    // -5.8 % at 858 k: the switch sits at ~12 MiB of would-be binary nodes, half a million primitives)
+    const bool big = n_prims * sizeof(DevNode) / 2 >= (12ull << 20);
     const bool wide = fits && ctx->opt_kernel_wide_ok() && (ctx->opt_node_format == 3 || ctx->opt_node_format == 4 || (ctx->opt_node_format == 0 && big));
     // 64-byte records (format 4) unless the 80-byte ones are asked for; they address 2^26 nodes
     bool compact = wide && ctx->opt_node_format != 3;

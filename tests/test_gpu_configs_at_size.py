@@ -82,7 +82,7 @@ def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_wide
         got, hits = ctx.accum_download(), ctx.aov_download()
     assert st.pixel_frames == w * h
     assert st.rays == cnt.rays, (st.rays, cnt.rays)
-    # the node format chosen by size (RT_OPT_NODE_FORMAT = 0): 64-byte 8-ary nodes once the nodes would exceed 16 MB
+    # the node format chosen by size (RT_OPT_NODE_FORMAT = 0): 64-byte 8-ary nodes once the binary nodes would exceed 12 MiB
     per_node = (st.bvh_bytes - n_prims * (48 + 128)) / st.bvh_nodes
     assert (per_node == 64) == expect_wide, per_node
     assert np.array_equal(hits, want_hits), f"{int((hits != want_hits).any(axis=-1).sum())} primary hit ids differ"
