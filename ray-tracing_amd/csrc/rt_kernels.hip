@@ -933,7 +933,15 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
 #ifdef RT_EXP_NODE_LOAD      // sensitivity builds: N extra 16-byte fetches of the node's own first chunk (same cache line)
                     {
 #pragma unroll
-                      for (int q = 0; q < RT_EXP_NODE_LOAD; q++) { float4 dmy; asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(dmy) : "v"(n) : "memory"); }
+                      for (int q = 0; q < RT_EXP_NODE_LOAD; q++) { float4 dmy; 
+#if defined(RT_EXP_NODE_LOAD_HOT)      /* a different, L1-resident line per lane (the top of the tree), not waited for by itself */
+                          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dmy) : "v"(nodes + 3u * (lane ^ (uint32_t)q * 17u)) : "memory");
+#elif defined(RT_EXP_NODE_LOAD_NOWAIT)   /* issued ahead of the node's own fetches and never waited for by itself: an older load only makes the compiler's vmcnt waits longer */
+                          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dmy) : "v"(n) : "memory");
+#else
+                          asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(dmy) : "v"(n) : "memory");
+#endif
+                      }
                     }
 #endif
                     // rotate amounts: bits 4:0 of the stuffed inverse (see start_trace), 16 for a negative direction
