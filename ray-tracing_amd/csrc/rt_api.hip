@@ -160,6 +160,7 @@ struct rt_context {
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
     float sah_traversal_cost = 1.0f; // key 110, in 1/16
     uint32_t bvh_max_depth = 0;      // key 111, 0 = builder default
+    bool collapse_greedy = false;    // key 112: 8-ary collapse by the greedy rule instead of the cost-optimal cut (measurement)
     uint64_t stage_budget = 4ull << 30;   // bytes of staging a multi-frame launch may use (key 109, tests)
     uint32_t chunk = 0;              // queue grain in pixel slots; 0 = by the amount of work (see launch())
     bool timed = false;
@@ -195,6 +196,7 @@ struct Repacked {
     bool compact = false;            // wide: 64-byte records (DevNode8c) in `nodes8c`, node_stride 4
     std::vector<DevNode8c> nodes8c;
     float grid_lo[3] = {0.0f, 0.0f, 0.0f}, grid_cell[3] = {1.0f, 1.0f, 1.0f};   // compact: the corner grid (rt_pack.h rt_grid_for)
+    bool collapse_dp = true;         // wide: cost-optimal cut of the BVH2 (false: greedy, largest area first)
     int width8 = 8;                  // wide: children a node may hold (developer knob 105: what a narrower tree would visit)
     std::vector<uint32_t> order8;    // wide: slot -> primitive id (a node's leaf children are consecutive slots)
     std::vector<int32_t> parent;     // node -> parent * 2 + child slot (device refit)
@@ -230,31 +232,91 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
     out.order8.assign(n_prims, 0u);
     uint64_t n_inner2 = 0;
     for (const auto &n : bvh.nodes) if (n.count == 0) n_inner2++;
-    if (out.compact) {
-        out.nodes8c.assign(n_inner2 + 1, DevNode8c());
-        memset(out.nodes8c.data(), 0, out.nodes8c.size() * sizeof(DevNode8c));
-    } else {
-        out.nodes8.assign(n_inner2 + 1, DevNode8());
-        memset(out.nodes8.data(), 0, out.nodes8.size() * sizeof(DevNode8));
-    }
-    out.parent.assign(n_inner2 + 1, -1);                 // node -> parent * 8 + child slot (device refit)
-    std::atomic<uint64_t> next_node{1}, next_slot{0};
-    std::atomic<uint32_t> max_depth{0};
-    struct Item { uint32_t src, dst, depth; };
-
     auto half_area = [](const rt_host::Aabb &b) {
         const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
         return (dx >= 0.0f && dy >= 0.0f && dz >= 0.0f) ? dx * dy + dy * dz + dz * dx : 0.0f;
     };
+    // Which BVH2 nodes become 8-ary nodes?  Every 8-ary node visited costs one node step whatever it holds and every primitive is
+    // some node's child whatever the cut, so the expected work is the summed surface area of the BVH2 nodes that are KEPT as
+    // 8-ary nodes.  Minimised exactly by dynamic programming over the BVH2 (Ylitie, Karras, Laine 2017, section 4.1):
+    //   T(n, i) = least area below n when n's subtree may use i child slots of its parent (i = 1: n itself becomes a node),
+    //   T(n, 1) = area(n) + min_k T(l, k) + T(r, W - k),   T(n, i) = min(T(n, i - 1), min_k T(l, k) + T(r, i - k)),
+    //   a leaf of c primitives: 0 with c slots or more, area(n) with fewer (a node of its own).
+    // Children follow their parents in bvh.nodes, so one backward sweep fills the table.  40 bytes per BVH2 node: trees beyond
+    // 2^28 nodes (and developer knob 112 = 1) use the greedy rule below (largest area first).
+    const int W = out.width8;
+    const bool dp = out.collapse_dp && bvh.nodes.size() > 1 && bvh.nodes.size() <= (1u << 28);
+    std::vector<float> T;
+    std::vector<uint8_t> pick_k;                            // [n * 8 + i]: i = 2..W-1: 0 = as with i - 1 slots, else k; i = W: k of T(n, 1)
+    if (dp) {
+        T.assign(bvh.nodes.size() * 8, 0.0f);
+        pick_k.assign(bvh.nodes.size() * 8, 0);
+        for (size_t n = bvh.nodes.size(); n-- > 0;) {
+            const rt_host::Bvh2Node &nd = bvh.nodes[n];
+            float *t = &T[n * 8];
+            const float area = half_area(nd.box);
+            if (nd.count) {
+                for (int i = 1; i < 8; i++) t[i] = i >= (int)nd.count ? 0.0f : area;
+                continue;
+            }
+            const float *tl = &T[(size_t)nd.left * 8], *tr = tl + 8;
+            auto distribute = [&](int j, uint8_t &k_out) {
+                float best = 3.4e38f;
+                for (int k = 1; k < j; k++) {
+                    const float c = tl[k] + tr[j - k];
+                    if (c < best) { best = c; k_out = (uint8_t)k; }
+                }
+                return best;
+            };
+            t[1] = area + distribute(W, pick_k[n * 8 + (W & 7)]);
+            for (int i = 2; i < W; i++) {
+                uint8_t k = 0;
+                const float d = distribute(i, k);
+                if (d < t[i - 1]) { t[i] = d; pick_k[n * 8 + i] = k; } else { t[i] = t[i - 1]; pick_k[n * 8 + i] = 0; }
+            }
+            for (int i = W; i < 8; i++) t[i] = t[W - 1];
+        }
+    }
+    const uint64_t n_nodes_max = dp ? bvh.nodes.size() : n_inner2 + 1;
+    if (out.compact) {
+        out.nodes8c.assign(n_nodes_max, DevNode8c());
+        memset(out.nodes8c.data(), 0, out.nodes8c.size() * sizeof(DevNode8c));
+    } else {
+        out.nodes8.assign(n_nodes_max, DevNode8());
+        memset(out.nodes8.data(), 0, out.nodes8.size() * sizeof(DevNode8));
+    }
+    out.parent.assign(n_nodes_max, -1);                  // node -> parent * 8 + child slot (device refit)
+    std::atomic<uint64_t> next_node{1}, next_slot{0};
+    std::atomic<uint32_t> max_depth{0};
+    struct Item { uint32_t src, dst, depth; };
+
     // one node: fills out.nodes8[it.dst], appends its inner children to `todo`
     auto process = [&](const Item &it, std::vector<Item> &todo) {
         uint32_t open[8];
+        bool kept[8] = {false, false, false, false, false, false, false, false};      // this BVH2 node stays a node (an inner child)
         int n_open = 0, total = 0;
         auto size_of = [&](uint32_t i) { return bvh.nodes[i].count ? (int)bvh.nodes[i].count : 1; };
         const rt_host::Bvh2Node &src = bvh.nodes[it.src];
         if (src.count || bvh.nodes.size() == 1) { open[n_open++] = it.src; total = (int)src.count; }      // the whole scene is one leaf (or empty)
-        else { open[0] = src.left; open[1] = src.left + 1; n_open = 2; total = size_of(open[0]) + size_of(open[1]); }
-        for (;;) {
+        else if (dp) {
+            struct Grant { uint32_t node; int slots; } work[16];
+            int n_work = 0;
+            const int k = pick_k[(size_t)it.src * 8 + (W & 7)];
+            work[n_work++] = {src.left + 1u, W - k};
+            work[n_work++] = {src.left, k};
+            while (n_work) {
+                const Grant g = work[--n_work];
+                const rt_host::Bvh2Node &c = bvh.nodes[g.node];
+                int i = g.slots;
+                if (c.count) { kept[n_open] = i < (int)c.count; open[n_open++] = g.node; continue; }
+                while (i > 1 && pick_k[(size_t)g.node * 8 + i] == 0) i--;
+                if (i == 1) { kept[n_open] = true; open[n_open++] = g.node; continue; }
+                const int kk = pick_k[(size_t)g.node * 8 + i];
+                work[n_work++] = {c.left + 1u, i - kk};
+                work[n_work++] = {c.left, kk};
+            }
+        } else { open[0] = src.left; open[1] = src.left + 1; n_open = 2; total = size_of(open[0]) + size_of(open[1]); }
+        for (; !dp;) {
             int pick = -1;
             float best = -1.0f;
             for (int i = 0; i < n_open; i++) {
@@ -276,7 +338,7 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
         int n_ch = 0;
         for (int i = 0; i < n_open; i++) {
             const rt_host::Bvh2Node &c = bvh.nodes[open[i]];
-            if (!c.count && !(bvh.nodes.size() == 1)) { ch[n_ch++] = {true, open[i], c.box}; continue; }
+            if (dp ? kept[i] : (!c.count && !(bvh.nodes.size() == 1))) { ch[n_ch++] = {true, open[i], c.box}; continue; }
             for (uint32_t k = 0; k < c.count && n_ch < 8; k++) {
                 const uint32_t prim = bvh.order[c.left + k];
                 ch[n_ch++] = {false, prim, prim_boxes[prim]};
@@ -648,6 +710,7 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     // nodes are too many to stay in the caches (measured: C4, 244 MB of 48-byte nodes, 8 % faster; C3, 0.26 MB, 2 % slower)
     rp.wide = wide;
     rp.compact = compact;
+    rp.collapse_dp = !ctx->collapse_greedy;
     rp.width8 = (ctx->tune[5] >= 4 && ctx->tune[5] <= 8) ? ctx->tune[5] : 8;
     rp.q8 = !wide && fits && ctx->opt_node_format == 2;
     if (rp.q8) rp.node_stride = 2;
@@ -1063,7 +1126,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             return RT_OK;
         default:
             // developer knobs (tools/ab_bench.py, tools/shard_scaling.py): 100..107 scheduler weights (103: resident workgroups per CU, 0 = all that fit) and builder leaf size /
-            // bins, 108 queue grain, 109 staging budget in KiB, 110 SAH traversal cost x16, 111 BVH depth cap
+            // bins, 108 queue grain, 109 staging budget in KiB, 110 SAH traversal cost x16, 111 BVH depth cap, 112 greedy 8-ary collapse
             if (key == 106 && (value < 0 || value > 7)) return fail(RT_ERR_INVALID_ARGUMENT, "option 106 (triangles per leaf): 0..7");
             // a phase weight of 0 would let the scheduler pick a phase nobody waits in, for ever
             if ((key == 100 || key == 101 || key == 102 || key == 104) && (value < 1 || value > 65536))
@@ -1075,6 +1138,7 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             }
             if (key == 108 && value >= 0 && value <= 1024) { ctx->chunk = (uint32_t)value; return RT_OK; }
             if (key == 111 && value >= 0 && value <= 48) { ctx->bvh_max_depth = (uint32_t)value; return RT_OK; }
+            if (key == 112 && (value == 0 || value == 1)) { ctx->collapse_greedy = value == 1; return RT_OK; }
             if (key == 110 && value >= 0) { ctx->sah_traversal_cost = (float)value / 16.0f; return RT_OK; }
             if (key == 109 && value >= 1) { ctx->stage_budget = (uint64_t)value << 10; return RT_OK; }   // KiB
             return fail(RT_ERR_INVALID_ARGUMENT, "unknown option %d", key);

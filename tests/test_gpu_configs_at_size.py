@@ -94,7 +94,7 @@ def test_c4_full_scene_matches_oracle(rt, oracle_mod, obj_loader, capsys):
     """C4: 1,059 baked teapots (9.99 M triangles) + 100,000 spheres, 160x90, 16 spp, 8 bounces."""
     with heartbeat(capsys, "C4 10M"):
         st = _against_oracle(rt, oracle_mod, obj_loader, "C4", 160, 90, 16, expect_wide=True)
-    assert st.bvh_nodes > 2_000_000 and st.stack_entries >= 16
+    assert st.bvh_nodes > 10_090_000 // 8 and st.stack_entries >= 16        # at most 8 children per node
 
 
 def test_c5q_50m_triangles_match_oracle(rt, oracle_mod, obj_loader, capsys):

@@ -43,3 +43,34 @@ def test_8ary_format_is_really_used(rt, scenes):
     assert sizes[1][1] == 48 and sizes[3][1] == 80 and sizes[4][1] == 64
     assert sizes[3][0] < sizes[1][0] / 1.8 and sizes[4][0] == sizes[3][0]
     assert sizes[3][2] <= 24 and sizes[4][2] == sizes[3][2]
+
+
+@pytest.mark.parametrize("fmt", [3, 4])
+def test_collapse_cut_optimal_vs_greedy(rt, scenes, fmt):
+    """The 8-ary tree is cut out of the BVH2 by dynamic programming (fewest expected node visits); developer knob 112 = 1 gives the
+    older greedy cut.  Both are trees over the same primitives, so the images agree bit for bit, and the optimal cut needs fewer
+    nodes and fewer node visits per ray."""
+    import numpy as np
+    from conftest import config
+    s = scenes("teapot-circle")
+    cfg = config("C3")
+    W, H = 160, 90
+    u = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], max_bounces=4, samples=2)
+    got = {}
+    for greedy in (0, 1):
+        with rt.Context(0) as ctx:
+            ctx.set_option(rt.RT_OPT_NODE_FORMAT, fmt)
+            ctx.set_option(112, greedy)
+            ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+            ctx.set_option(rt.RT_OPT_COUNT_TRAVERSAL, 1)
+            ctx.accum_resize(W, H)
+            ctx.dispatch(u)
+            st = ctx.stats()
+            got[greedy] = (np.array(ctx.accum_download(), copy=True), st.bvh_nodes, st.node_visits, st.rays)
+    assert got[0][0].tobytes() == got[1][0].tobytes()
+    assert got[0][3] == got[1][3]
+    assert got[0][1] < got[1][1], (got[0][1], got[1][1])
+    assert got[0][2] < got[1][2], (got[0][2], got[1][2])
+    with rt.Context(0) as ctx:
+        with pytest.raises(rt.RtError):
+            ctx.set_option(112, 2)
