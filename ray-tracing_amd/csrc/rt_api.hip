@@ -154,7 +154,7 @@ struct rt_context {
     // the 8-ary format is traversed by every kernel variant
     bool opt_kernel_wide_ok() const { return true; }
     int opt_kernel = 2;
-    int32_t tune[8] = {3, 4, 2, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE, workgroups per CU (0 = all that fit), FETCH weight, children per 8-ary node (4..8, else 8), builder max_leaf, bins
+    int32_t tune[8] = {0, 0, 0, 0, 64, 0, 0, 0};   // keys 100..107: phase weights NODE/LEAF/SHADE (0 = by scene size, see launch), workgroups per CU (0 = all that fit), FETCH weight, children per 8-ary node (4..8, else 8), builder max_leaf, bins
     float4 *d_stage = nullptr;       // per-frame sample sums of a multi-frame launch (lazy, grows)
     uint64_t stage_elems = 0;
     int opt_pipeline = 1;            // RT_OPT_FRAME_PIPELINE
@@ -914,6 +914,15 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
     P.n_slots = ctx->n_tris;
     P.queue = static_scratch ? reinterpret_cast<DevQueue *>(static_scratch) : ctx->d_queue;
     memcpy(P.tune, ctx->tune, sizeof P.tune);
+    {
+        // Scheduler weights (which phase a wave runs next = the one with the most waiting lanes x weight).  Scenes whose nodes stay in the
+        // caches: 3 / 4 / 2, a SHADE step is dear and runs best on full waves.  Scenes past the size at which the node format
+        // switches too (host_build): 2 / 4 / 6 — there a node step is a trip to L2 or HBM, and rays that sit waiting to be shaded
+        // are round trips not in flight (C4 91.0 -> 86.2, C5q 53.2 -> 49.8, C5 472 -> 436 ms per step; C3: 15.28 -> 15.9 the other way).
+        const bool far_nodes = (uint64_t)ctx->n_tris * sizeof(DevNode) / 2 >= (12ull << 20);
+        const int32_t by_size[3] = {far_nodes ? 2 : 3, 4, far_nodes ? 6 : 2};
+        for (int k = 0; k < 3; k++) if (P.tune[k] <= 0) P.tune[k] = by_size[k];
+    }
     // queue grain: 64 slots (one 8x8 tile) keeps the end of a launch short, which is what counts for a shard of
     // the image; a whole 4K image takes two tiles per claim (measured: 16.8 -> 16.5 ms/step at 8.3 M slots per
     // frame, but 8.46 -> 8.65 ms/step at 4.1 M, so the switch sits between the two)
