@@ -48,9 +48,20 @@ def cpu_baseline_and_byte_model(cfg, sample_w, sample_h):
     u = oracle.make_uniform(sample_w, sample_h, cfg["position"], cfg["yaw"], cfg["pitch"],
                             aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]),
                             max_bounces=cfg["max_bounces"], samples=cfg["samples"])
+    import threading
+    done = threading.Event()
+
+    def heartbeat():            # the big configs' sample frame takes minutes on the CPU: say so (stderr; stdout carries the JSON line only)
+        while not done.wait(30.0):
+            print(f"[bench] cpu_baseline sample still rendering ({time.perf_counter() - t0:.0f} s)", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    img, _, cnt = sc.render(u, mode=1)
-    dt = time.perf_counter() - t0
+    hb = threading.Thread(target=heartbeat, daemon=True)
+    hb.start()
+    try:
+        img, _, cnt = sc.render(u, mode=1)
+    finally:
+        dt = time.perf_counter() - t0
+        done.set()
     threads = int(oracle.lib().oracle_threads())       # omp_get_max_threads() of the library that just rendered
     n_node = cnt.node_visits / cnt.rays
     n_tri = cnt.triangle_tests / cnt.rays
