@@ -820,7 +820,12 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
     uint32_t ng_base = 0, ng_mask = 0, tg_base = 0, tg_mask = 0, flip256 = 0;
     uint32_t *sptr = stack;   // next free entry of the lane's LDS stack (entries are kBlock words apart)
     unsigned guard_steps = 0; // RT_GUARD: traversal steps of the current ray
-    uint32_t *const stack_end = stack + (size_t)P.stack_entries * kBlock;
+    // 8-ary nodes: an entry is a group = (base, 16-bit mask), 6 bytes: the bases of all levels in one plane of words, the masks in a
+    // plane of halfwords behind it, both indexed [level * kBlock + thread] (P.stack_entries counts words of the 8-byte entries the
+    // other kernel variants keep: two per level).  C4: 13 levels x 6 B x 256 lanes = 19.5 KB instead of 26 KB per workgroup.
+    const uint32_t stack_levels = WIDE ? P.stack_entries / 2u : P.stack_entries;
+    uint32_t *const stack_end = stack + (size_t)stack_levels * kBlock;
+    unsigned short *const mask_plane = reinterpret_cast<unsigned short *>(lds_stack + (size_t)stack_levels * kBlock);
     uint32_t w_next = 0, w_end = 0;   // the wave's claimed chunk, wave-uniform
     bool drained = false;
 
@@ -850,7 +855,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
         if (tg_mask & 0xffu) phase = PH_LEAF;
         else if (ng_mask & 0xffu) phase = PH_NODE;
         else if (sptr == stack) phase = PH_SHADE;
-        else { sptr -= 2 * kBlock; ng_base = sptr[0]; ng_mask = sptr[kBlock]; phase = PH_NODE; }
+        else { sptr -= kBlock; ng_base = sptr[0]; ng_mask = mask_plane[sptr - lds_stack]; phase = PH_NODE; }
     };
     // wave-uniform choice of the next phase body: the one most lanes wait for,
     // weighted (P.tune) so cheap bodies run at lower occupancy than expensive ones
@@ -895,8 +900,8 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                         if (kGuard && (node + (COMPACT ? 4u : 5u) > P.n_node_chunks || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
                         else {
                             if (ng_mask & 0xffu) {               // siblings still to visit: the group goes on the stack
-                                if (kGuard && sptr + kBlock >= stack_end) { tl.guard++; }
-                                else { sptr[0] = ng_base; sptr[kBlock] = ng_mask; sptr += 2 * kBlock; }
+                                if (kGuard && sptr >= stack_end) { tl.guard++; }
+                                else { sptr[0] = ng_base; mask_plane[sptr - lds_stack] = (unsigned short)ng_mask; sptr += kBlock; }
                             }
                             if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
 #ifdef RT_EXP_NODE_VALU      // sensitivity builds (tools/sensitivity.sh)
@@ -1215,7 +1220,7 @@ int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool ao
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
-    const size_t lds = (size_t)stack_entries * kBlock * sizeof(uint32_t);
+    const size_t lds = fmt >= 2 ? (size_t)(stack_entries / 2u) * kBlock * 6u : (size_t)stack_entries * kBlock * sizeof(uint32_t);
     // the instances differ in register count (and static LDS), hence in how many workgroups fit
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
     const void *fn;
@@ -1244,8 +1249,14 @@ static hipError_t launch_phased(const RenderParams &P, dim3 grid, size_t lds, hi
 
 // variant 2 (and the blend of a multi-frame launch).  Lives in its own translation unit: see the Makefile on
 // -structurizecfg-skip-uniform-regions.
+// dynamic LDS of the phased kernel: binary nodes one word per stack entry; 8-ary nodes 6 bytes per level (see rt_render_phased)
+static size_t phased_lds_bytes(uint32_t stack_entries, bool wide) {
+    return wide ? (size_t)(stack_entries / 2u) * kBlock * 6u : (size_t)stack_entries * kBlock * sizeof(uint32_t);
+}
+
 hipError_t rt_launch_phased(const RenderParams &P, bool count, bool aov, bool spheres, unsigned blocks, size_t lds, hipStream_t stream) {
     const dim3 grid(blocks);
+    lds = phased_lds_bytes(P.stack_entries, P.node_wide != 0u);
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
     hipError_t e = hipSuccess;
     switch (sel) {
