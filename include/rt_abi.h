@@ -170,6 +170,8 @@ typedef struct RtStats {
     uint32_t resident_blocks; /* workgroups of 256 the persistent kernel keeps resident (0 before the first launch) */
     uint64_t guard_trips;     /* librt_amd_guard.so only (make guard: every traversal reference range-checked, steps capped):
                                  rays ended by a failed check.  Always 0 in the shipping library, which compiles no checks. */
+    uint32_t node_format;     /* static: the node record the uploaded scene actually got (RT_OPT_NODE_FORMAT values 1..4; 0 = no scene) */
+    uint32_t pad0;
 } RtStats;
 
 /* rt_set_option keys */
@@ -290,10 +292,20 @@ int rt_frames_reserve(rt_context *ctx, uint32_t n_frames);
  * until the process ends.  The whole run is ONE launch, so n_frames x local_rows x w x 16 bytes must fit that
  * array (n_frames = 1 stages nothing and fits at any size); a bigger request fails with
  * RT_ERR_INVALID_ARGUMENT and a message naming both sizes, nothing is rendered.  RT_OPT_AOV must be off (its
- * buffer is allocated on demand).  All contexts on one GPU share that GPU's array: calls that overlap on one
- * GPU (two contexts, two streams) race; calls on one stream, or separated by rt_sync, do not. */
+ * buffer is allocated on demand).  All contexts on one GPU share that GPU's array, which keeps the last call's
+ * contents (the call clears what must start at zero).  The library serialises them: every call makes its stream wait
+ * (hipStreamWaitEvent on a per-GPU event created in rt_create — no allocation) for the static call before it on
+ * that GPU, whichever context and stream issued it, so two contexts cannot corrupt each other's launch; they run
+ * one after the other.  The exception is a call recorded under hipStreamBeginCapture: nothing can be waited for
+ * inside a capture, so the owner of the graph orders its launches against other static calls on that GPU (and the
+ * timing events are not recorded: rt_last_dispatch_ms does not see a captured call).  Calls from several host
+ * threads on DIFFERENT contexts are safe; one context is for one thread, as everywhere in this API. */
 #define RT_STATIC_STAGE_BYTES (32ull << 20)
 int rt_dispatch_frames_static(rt_context *ctx, RtUniform *uniform, uint32_t n_frames);
+/* Test hook, no counterpart in the reference: hipMalloc calls this library has made in this process so far (every
+ * device allocation of the library is counted).  tests/test_zz_no_alloc.py asserts that it does not move across
+ * rt_dispatch_frames_static. */
+uint64_t rt_debug_alloc_count(void);
 int rt_sync(rt_context *ctx);
 
 /* ---------------------------------------------------------------- readback */
@@ -332,6 +344,13 @@ typedef struct rt_group rt_group;
 int rt_group_create(const int *device_ids, int n_devices, rt_group **out);
 int rt_group_destroy(rt_group *g);
 int rt_group_size(const rt_group *g);
+/* How shard i's bands reach device_ids[0] in a download: status[i] for i < rt_group_size (n = room in status[]).
+ * The gather is correct in every case; without peer access HIP stages the copy through host memory. */
+#define RT_PEER_SAME_DEVICE   0   /* shard i renders on device_ids[0] itself */
+#define RT_PEER_ENABLED       1   /* hipDeviceEnablePeerAccess succeeded: GPU-to-GPU copy over xGMI */
+#define RT_PEER_UNAVAILABLE   2   /* hipDeviceCanAccessPeer says no: host-staged copy */
+#define RT_PEER_ENABLE_FAILED 3   /* peer access exists but could not be enabled: host-staged copy */
+int rt_group_peer_access(const rt_group *g, int *status, int n);
 int rt_group_context(rt_group *g, int shard, rt_context **out);
 int rt_group_set_option(rt_group *g, int key, int64_t value);
 int rt_group_scene_upload(rt_group *g,

@@ -48,6 +48,10 @@ SPHERE_DTYPE = np.dtype(
      "formats": [(np.float32, 3), np.float32, np.uint32],
      "offsets": [0, 12, 16], "itemsize": 32})
 
+# Test hook of THIS binding, not of the library (tests/test_gpu_wide_nodes.py repeats the parity suite on the 8-ary formats in a
+# child process): RT_AMD_NODE_FORMAT=0..4 makes every Context / Group created here start with that RT_OPT_NODE_FORMAT.
+_TEST_NODE_FORMAT = int(os.environ["RT_AMD_NODE_FORMAT"]) if os.environ.get("RT_AMD_NODE_FORMAT", "") in ("0", "1", "2", "3", "4") else None
+
 RT_OPT_COUNT_TRAVERSAL = 1
 RT_OPT_AOV = 2
 RT_OPT_KERNEL = 3
@@ -63,6 +67,7 @@ EXPORTS = [
     "rt_set_shard", "rt_accum_local_rows", "rt_accum_resize", "rt_accum_bind",
     "rt_dispatch", "rt_dispatch_frames", "rt_dispatch_frames_static", "rt_frames_reserve", "rt_sync", "rt_capture_rgb8",
     "rt_accum_download", "rt_aov_download", "rt_stats", "rt_stats_reset", "rt_last_dispatch_ms",
+    "rt_debug_alloc_count", "rt_group_peer_access",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_context", "rt_group_set_option", "rt_group_scene_upload",
     "rt_group_spheres_upload", "rt_group_textures_upload", "rt_group_models_update", "rt_group_accum_resize", "rt_group_dispatch",
     "rt_group_dispatch_frames", "rt_group_sync", "rt_group_accum_download", "rt_group_capture_rgb8", "rt_group_stats", "rt_group_stats_reset",
@@ -117,7 +122,8 @@ class RtStats(C.Structure):
                 ("wave_steps", C.c_uint64), ("dispatches", C.c_uint64), ("bvh_nodes", C.c_uint64),
                 ("bvh_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double), ("bvh_refits", C.c_uint64),
                 ("bvh_rebuilds", C.c_uint64), ("launches", C.c_uint64),
-                ("stack_entries", C.c_uint32), ("resident_blocks", C.c_uint32), ("guard_trips", C.c_uint64)]
+                ("stack_entries", C.c_uint32), ("resident_blocks", C.c_uint32), ("guard_trips", C.c_uint64),
+                ("node_format", C.c_uint32), ("pad0", C.c_uint32)]
 
 
 class RtBvhInfo(C.Structure):
@@ -175,6 +181,9 @@ def lib():
         L.rt_group_destroy.argtypes = [vp]
         L.rt_group_size.argtypes = [vp]
         L.rt_group_context.argtypes = [vp, i32, C.POINTER(vp)]
+        L.rt_group_peer_access.argtypes = [vp, C.POINTER(C.c_int), i32]
+        L.rt_debug_alloc_count.restype = u64
+        L.rt_debug_alloc_count.argtypes = []
         L.rt_group_set_option.argtypes = [vp, i32, C.c_int64]
         L.rt_group_scene_upload.argtypes = [vp, vp, u64, vp, u64, vp, u32, vp, vp, u32]
         L.rt_group_spheres_upload.argtypes = [vp, vp, u64]
@@ -321,6 +330,8 @@ class Context:
         _check(lib().rt_create(device, C.byref(h)))
         self.handle = h
         self.width = self.height = 0
+        if _TEST_NODE_FORMAT is not None:
+            self.set_option(RT_OPT_NODE_FORMAT, _TEST_NODE_FORMAT)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -450,6 +461,8 @@ class Group:
         _check(lib().rt_group_create(ids, len(device_ids), C.byref(h)))
         self.handle = h
         self.width = self.height = 0
+        if _TEST_NODE_FORMAT is not None:
+            self.set_option(RT_OPT_NODE_FORMAT, _TEST_NODE_FORMAT)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -467,6 +480,13 @@ class Group:
 
     def __len__(self):
         return int(lib().rt_group_size(self.handle))
+
+    def peer_access(self):
+        """Per shard: RT_PEER_* (0 same device as shard 0, 1 peer access enabled, 2 unavailable, 3 enabling failed)."""
+        n = len(self)
+        st = (C.c_int * n)()
+        _check(lib().rt_group_peer_access(self.handle, st, n))
+        return list(st)
 
     def set_option(self, key, value):
         _check(lib().rt_group_set_option(self.handle, key, int(value)))

@@ -39,6 +39,8 @@ hipError_t rt_launch_refit8(DevTri *tris, const DevShade *shade, const float *xf
                             uint32_t stride, const int32_t *parent, unsigned int *arrived, RtRefitBox *cbox, uint32_t n_nodes,
                             RtRefitBox *root_out, float prim_pad, const float *grid_lo_cell, hipStream_t stream);
 
+static std::atomic<uint64_t> g_device_allocs{0};   // hipMalloc calls this library has made (rt_debug_alloc_count; tests/test_zz_no_alloc.py)
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -59,6 +61,12 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// every device allocation of the library goes through here, so that a test can prove a call path makes none
+hipError_t dev_malloc(void **p, size_t bytes) {
+    g_device_allocs.fetch_add(1, std::memory_order_relaxed);
+    return hipMalloc(p, bytes);
+}
+
 template <typename T>
 void dev_free(T *&p) {
     if (p) (void)hipFree(p);
@@ -76,7 +84,15 @@ void dev_free(T *&p) {
 #define RT_STATIC_HEADER_BYTES 256u
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_HEADER_BYTES + RT_STATIC_STAGE_BYTES];
 #define RT_MAX_DEVICES 64
-static void *g_scratch_ptr[RT_MAX_DEVICES];        // per device: address of `scratch` there, null until rt_create ran on it
+// Per device, set up once (under g_scratch_mutex) by the first rt_create on it: the address of `scratch` there, and the event that
+// orders the users of that one array.  Every static dispatch makes its stream wait for the event of the static dispatch before it
+// on that GPU (whatever context and stream that was) and records its own behind its last kernel, so two contexts on one GPU
+// cannot zero each other's live queue head or overwrite each other's staging planes.  Neither call allocates.
+#include <mutex>
+static std::mutex g_scratch_mutex;
+static void *g_scratch_ptr[RT_MAX_DEVICES];
+static hipEvent_t g_scratch_done[RT_MAX_DEVICES];
+static bool g_scratch_used[RT_MAX_DEVICES];        // g_scratch_done[d] has been recorded at least once
 
 // Host copy of the scene inputs (rt_models_update rebuilds from them) and the host BVH.  One per context, or ONE shared
 // by all the contexts of an rt_group: the scene is loaded, built and repacked once, however many GPUs render it.
@@ -588,6 +604,7 @@ struct Built {
     uint64_t n_prims = 0;
     double build_seconds = 0.0;
     float prim_pad_scale = 0.0f;
+    bool valid = false;                  // host_build filled it
 };
 
 // Host half: validate, gather triangles, build (or refit) the BVH2 in ctx->hs, repack it.  Touches no device state.
@@ -730,6 +747,7 @@ int host_build(rt_context *ctx, bool allow_refit, Built &out) {
     }
     out.build_seconds = bvh.build_seconds;
     out.n_prims = n_prims;
+    out.valid = true;
     convert_materials(*ctx, out.mats);
     if (rp.wide && !rp.compact && rp.node_stride != RT_NODE8_CHUNKS) {
         const size_t pitch = (size_t)rp.node_stride * 16u;
@@ -760,10 +778,10 @@ int device_upload(rt_context *ctx, const Built &b) {
     dev_free(ctx->d_nodes); dev_free(ctx->d_tris); dev_free(ctx->d_shade); dev_free(ctx->d_materials);
     const size_t n_nodes = rp.compact ? rp.nodes8c.size() : (rp.wide ? rp.nodes8.size() : rp.nodes.size());
     const size_t node_bytes = n_nodes * (size_t)rp.node_stride * 16u;
-    RT_HIP(hipMalloc((void **)&ctx->d_nodes, node_bytes));
-    RT_HIP(hipMalloc((void **)&ctx->d_tris, rp.tris.size() * sizeof(DevTri)));
-    RT_HIP(hipMalloc((void **)&ctx->d_shade, rp.shade.size() * sizeof(DevShade)));
-    RT_HIP(hipMalloc((void **)&ctx->d_materials, mats.size() * sizeof(DevMaterial)));
+    RT_HIP(dev_malloc((void **)&ctx->d_nodes, node_bytes));
+    RT_HIP(dev_malloc((void **)&ctx->d_tris, rp.tris.size() * sizeof(DevTri)));
+    RT_HIP(dev_malloc((void **)&ctx->d_shade, rp.shade.size() * sizeof(DevShade)));
+    RT_HIP(dev_malloc((void **)&ctx->d_materials, mats.size() * sizeof(DevMaterial)));
     ctx->materials_capacity = mats.size();
     const void *node_src = rp.compact ? (const void *)rp.nodes8c.data() : rp.wide ? (rp.node_stride == RT_NODE8_CHUNKS ? (const void *)rp.nodes8.data() : (const void *)b.packed_nodes.data())
                                    : (rp.node_stride == RT_NODE_CHUNKS ? (const void *)rp.nodes.data() : (const void *)b.packed_nodes.data());
@@ -778,12 +796,12 @@ int device_upload(rt_context *ctx, const Built &b) {
     dev_free(ctx->d_parent); dev_free(ctx->d_arrived); dev_free(ctx->d_cbox); dev_free(ctx->d_tribox); dev_free(ctx->d_root); dev_free(ctx->d_xform);
     if (ctx->opt_refit == 2 && rp.refit_sources_agree && rp.parent.size() == n_nodes && (rp.wide || n_nodes > 1)) {
         const size_t nn = n_nodes;
-        RT_HIP(hipMalloc((void **)&ctx->d_parent, nn * sizeof(int32_t)));
-        RT_HIP(hipMalloc((void **)&ctx->d_arrived, nn * sizeof(unsigned int)));
-        RT_HIP(hipMalloc((void **)&ctx->d_cbox, (rp.wide ? 8 : 2) * nn * sizeof(RtRefitBox)));
-        RT_HIP(hipMalloc((void **)&ctx->d_tribox, rp.tris.size() * sizeof(RtRefitBox)));
-        RT_HIP(hipMalloc((void **)&ctx->d_root, sizeof(RtRefitBox)));
-        RT_HIP(hipMalloc((void **)&ctx->d_xform, (ctx->hs->primitives.size() ? ctx->hs->primitives.size() : 1) * 12 * sizeof(float)));
+        RT_HIP(dev_malloc((void **)&ctx->d_parent, nn * sizeof(int32_t)));
+        RT_HIP(dev_malloc((void **)&ctx->d_arrived, nn * sizeof(unsigned int)));
+        RT_HIP(dev_malloc((void **)&ctx->d_cbox, (rp.wide ? 8 : 2) * nn * sizeof(RtRefitBox)));
+        RT_HIP(dev_malloc((void **)&ctx->d_tribox, rp.tris.size() * sizeof(RtRefitBox)));
+        RT_HIP(dev_malloc((void **)&ctx->d_root, sizeof(RtRefitBox)));
+        RT_HIP(dev_malloc((void **)&ctx->d_xform, (ctx->hs->primitives.size() ? ctx->hs->primitives.size() : 1) * 12 * sizeof(float)));
         RT_HIP(hipMemcpy(ctx->d_parent, rp.parent.data(), nn * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     RT_HIP(hipMemcpy(ctx->d_tris, rp.tris.data(), rp.tris.size() * sizeof(DevTri), hipMemcpyHostToDevice));
@@ -798,8 +816,11 @@ int device_upload(rt_context *ctx, const Built &b) {
     return RT_OK;
 }
 
-int build_and_upload(rt_context *ctx, bool allow_refit = false) {
-    Built b;
+// `keep`: where an rt_group wants the host half's result left, so that its other devices upload the same build
+int build_and_upload(rt_context *ctx, bool allow_refit = false, Built *keep = nullptr) {
+    Built local;
+    Built &b = keep ? *keep : local;
+    b = Built();
     int r = host_build(ctx, allow_refit, b);
     return r ? r : device_upload(ctx, b);
 }
@@ -818,7 +839,7 @@ int ensure_aov(rt_context *ctx) {
     uint64_t elems = (uint64_t)ctx->local_bands * 8u * ctx->width;
     if (ctx->d_aov && ctx->aov_elems == elems) return RT_OK;
     dev_free(ctx->d_aov);
-    RT_HIP(hipMalloc((void **)&ctx->d_aov, (elems ? elems : 1) * sizeof(RtHitId)));
+    RT_HIP(dev_malloc((void **)&ctx->d_aov, (elems ? elems : 1) * sizeof(RtHitId)));
     RT_HIP(hipMemsetAsync(ctx->d_aov, 0xFF, (elems ? elems : 1) * sizeof(RtHitId), ctx->stream));
     ctx->aov_elems = elems;
     return RT_OK;
@@ -847,15 +868,15 @@ int ensure_stage(rt_context *ctx, uint32_t n_frames) {
     RT_HIP(hipStreamSynchronize(ctx->stream));
     dev_free(ctx->d_stage);
     ctx->stage_elems = 0;
-    RT_HIP(hipMalloc((void **)&ctx->d_stage, need * sizeof(float4)));
+    RT_HIP(dev_malloc((void **)&ctx->d_stage, need * sizeof(float4)));
     ctx->stage_elems = need;
     return RT_OK;
 }
 
 // static_scratch: the queue head and the staging planes live in this device's `scratch` array (rt_dispatch_frames_static,
 // which has checked that they fit); nothing is allocated on that path.
-int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned char *static_scratch = nullptr) {
-    RenderParams P;
+// the kernel arguments of a launch of n_frames frames starting at uniform u
+int make_params(rt_context *ctx, const RtUniform &u, uint32_t n_frames, unsigned char *static_scratch, RenderParams &P) {
     memset(&P, 0, sizeof P);
     P.n_frames = n_frames;
     P.local_rows = (uint32_t)local_rows_for(ctx->height, ctx->shard_index, ctx->shard_count);
@@ -927,6 +948,12 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
     // the image; a whole 4K image takes two tiles per claim (measured: 16.8 -> 16.5 ms/step at 8.3 M slots per
     // frame, but 8.46 -> 8.65 ms/step at 4.1 M, so the switch sits between the two)
     P.chunk = ctx->chunk ? ctx->chunk : ((uint64_t)P.tiles_x * P.local_bands * 64u >= (6u << 20) ? 128u : 64u);
+    return RT_OK;
+}
+
+int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned char *static_scratch = nullptr) {
+    RenderParams P;
+    { int r = make_params(ctx, u, n_frames, static_scratch, P); if (r) return r; }
     if (ctx->opt_kernel != 1) {
         RT_HIP(hipMemsetAsync(P.queue, 0, sizeof(DevQueue), ctx->stream));     // the head must start at zero, whatever the last call left
         const bool ext = !ctx->hs->spheres.empty() || ctx->n_textures > 0;
@@ -948,7 +975,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
 #ifdef RT_TAIL_PROBE
     const size_t probe_waves = (size_t)(ctx->persistent_blocks > 0 ? ctx->persistent_blocks : 0) * 4;
     if (ctx->opt_kernel == 2 && n_frames > 1 && probe_waves && !static_scratch) {
-        RT_HIP(hipMalloc((void **)&P.probe, probe_waves * 24));
+        RT_HIP(dev_malloc((void **)&P.probe, probe_waves * 24));
         RT_HIP(hipMemsetAsync(P.probe, 0, probe_waves * 24, ctx->stream));
     }
 #endif
@@ -999,7 +1026,7 @@ int check_dispatch(rt_context *ctx, const RtUniform *u) {
 }
 
 // rt_models_update on the device (RT_OPT_REFIT = 2): new triangle records and node boxes without leaving the GPU.
-int device_refit(rt_context *ctx) {
+int device_refit(rt_context *ctx, Built *keep = nullptr) {
     auto t0 = std::chrono::steady_clock::now();
     RT_HIP(hipSetDevice(ctx->device));
     ctx->models_committed = true;
@@ -1037,9 +1064,9 @@ int device_refit(rt_context *ctx) {
     if (ctx->node_q8 || ctx->node_wide) {
         // the moved scene may have outgrown what 8-bit offsets can span (their outward rounding saturates there):
         // rebuild on the host, which chooses the node format again
-        if (!rt_q8_fits(root.lo, root.hi)) return build_and_upload(ctx, true);
+        if (!rt_q8_fits(root.lo, root.hi)) return build_and_upload(ctx, true, keep);
         // compact 8-ary nodes: their corners are cells of the grid laid out at the last host build; a scene that moved out of it is rebuilt
-        if (ctx->node_compact && !rt_grid_holds(root.lo, root.hi, ctx->grid_lo, ctx->grid_cell)) return build_and_upload(ctx, true);
+        if (ctx->node_compact && !rt_grid_holds(root.lo, root.hi, ctx->grid_lo, ctx->grid_cell)) return build_and_upload(ctx, true, keep);
     }
     return RT_OK;
 }
@@ -1058,24 +1085,26 @@ int rt_create(int device_id, rt_context **out) {
     if (e != hipSuccess || n == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device (%s)", hipGetErrorString(e));
     if (device_id < 0 || device_id >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device_id, n - 1);
     RT_HIP(hipSetDevice(device_id));
-    if (device_id < RT_MAX_DEVICES && !g_scratch_ptr[device_id]) {
-        // this device's copy of the static scratch array (rt_dispatch_frames_static); the device is current here
-        void *p = nullptr;
-        RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-        g_scratch_ptr[device_id] = p;
+    if (device_id < RT_MAX_DEVICES) {
+        // this device's copy of the static scratch array (rt_dispatch_frames_static) and the event that orders its users;
+        // the device is current here
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device_id]) {
+            void *p = nullptr;
+            hipEvent_t ev = nullptr;
+            RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            RT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            g_scratch_done[device_id] = ev;
+            g_scratch_ptr[device_id] = p;
+        }
     }
     rt_context *ctx = new rt_context();
     ctx->device = device_id;
-    // developer default for RT_OPT_NODE_FORMAT (tests/test_gpu_wide_nodes.py runs the whole parity suite on the 8-ary format this way)
-    if (const char *e = getenv("RT_AMD_NODE_FORMAT")) {
-        const int v = atoi(e);
-        if (v >= 0 && v <= 4) ctx->opt_node_format = v;
-    }
     (void)hipDeviceGetAttribute(&ctx->cu_count, hipDeviceAttributeMultiprocessorCount, device_id);
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_counters, sizeof(DevCounters)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_queue, sizeof(DevQueue)) != hipSuccess ||
+        dev_malloc((void **)&ctx->d_counters, sizeof(DevCounters)) != hipSuccess ||
+        dev_malloc((void **)&ctx->d_queue, sizeof(DevQueue)) != hipSuccess ||
         hipMemset(ctx->d_counters, 0, sizeof(DevCounters)) != hipSuccess) {
         rt_destroy(ctx);
         return fail(RT_ERR_HIP, "context set-up failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1210,15 +1239,18 @@ int rt_textures_upload(rt_context *ctx, const RtTexture *textures, uint32_t n_te
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
     dev_free(ctx->d_textures); dev_free(ctx->d_texels);
-    RT_HIP(hipMalloc((void **)&ctx->d_textures, table.size() * sizeof(DevTexture)));
-    RT_HIP(hipMalloc((void **)&ctx->d_texels, texels.size() * sizeof(uint32_t)));
+    RT_HIP(dev_malloc((void **)&ctx->d_textures, table.size() * sizeof(DevTexture)));
+    RT_HIP(dev_malloc((void **)&ctx->d_texels, texels.size() * sizeof(uint32_t)));
     RT_HIP(hipMemcpy(ctx->d_textures, table.data(), table.size() * sizeof(DevTexture), hipMemcpyHostToDevice));
     RT_HIP(hipMemcpy(ctx->d_texels, texels.data(), texels.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     ctx->n_textures = n_textures;
     return RT_OK;
 }
 
-int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models, const float *transforms) {
+}  // extern "C"
+
+// rt_models_update; `keep` (rt_group_models_update): receives the host build when the update needed one
+static int models_update_impl(rt_context *ctx, const RtGpuModel *models, uint32_t n_models, const float *transforms, Built *keep) {
     if (!ctx || (n_models && !models)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (!ctx->have_scene) return fail(RT_ERR_NO_SCENE, "rt_models_update before rt_scene_upload");
     if (n_models < ctx->hs->primitives.size())
@@ -1248,14 +1280,20 @@ int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_model
     ctx->last_update_on_device = false;
     if (ctx->opt_refit == 2 && ctx->d_parent && (ctx->n_nodes > 1 || ctx->node_wide) && ranges_kept && spheres_ok && n_models <= ctx->materials_capacity) {
         const uint64_t rebuilds_before = ctx->rebuilds, refits_before = ctx->refits;
-        r = device_refit(ctx);
+        r = device_refit(ctx, keep);
         ctx->last_update_on_device = r == RT_OK && ctx->rebuilds == rebuilds_before && ctx->refits == refits_before + 1;
-    } else r = build_and_upload(ctx, /*allow_refit=*/true);
+    } else r = build_and_upload(ctx, /*allow_refit=*/true, keep);
     if (r != RT_OK && !ctx->models_committed) {       // rejected before anything reached the device: the old scene stays in force
         old_models.swap(ctx->hs->models);
         if (transforms) old_transforms.swap(ctx->hs->transforms);
     }
     return r;
+}
+
+extern "C" {
+
+int rt_models_update(rt_context *ctx, const RtGpuModel *models, uint32_t n_models, const float *transforms) {
+    return models_update_impl(ctx, models, n_models, transforms, nullptr);
 }
 
 int rt_set_shard(rt_context *ctx, uint32_t shard_index, uint32_t shard_count) {
@@ -1289,7 +1327,7 @@ int rt_accum_resize(rt_context *ctx, uint32_t w, uint32_t h) {
     ctx->d_accum = nullptr;
     // whole bands are allocated so a partial last band needs no special case
     uint64_t bytes = (uint64_t)bands_for(h, ctx->shard_index, ctx->shard_count) * 8u * w * RT_ACCUM_STRIDE_BYTES;
-    RT_HIP(hipMalloc((void **)&ctx->d_accum, bytes ? bytes : 16));
+    RT_HIP(dev_malloc((void **)&ctx->d_accum, bytes ? bytes : 16));
     RT_HIP(hipMemsetAsync(ctx->d_accum, 0, bytes ? bytes : 16, ctx->stream));   // zeros, src/app.rs:90-92
     ctx->accum_owned = true;
     return setup_accum(ctx, w, h);
@@ -1385,7 +1423,17 @@ int rt_dispatch_frames_static(rt_context *ctx, RtUniform *uniform, uint32_t n_fr
         if (frame_slots * n_frames > kQueueIndexMax || n_frames > 65535u)
             return fail(RT_ERR_INVALID_ARGUMENT, "rt_dispatch_frames_static: %u frames exceed the 32-bit work queue of one launch", n_frames);
     }
-    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    // Under stream capture (hipStreamBeginCapture on the context's stream) the call is recorded, not run: the timing events and
+    // the cross-context ordering event are left out (an event recorded inside a capture cannot be waited on outside it); the
+    // owner of the graph orders its launches against other users of this GPU's scratch.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(ctx->stream, &cap);
+    const bool capturing = cap != hipStreamCaptureStatusNone;
+    if (!capturing) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (g_scratch_used[ctx->device]) RT_HIP(hipStreamWaitEvent(ctx->stream, g_scratch_done[ctx->device], 0));
+        RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    }
     uint32_t i = 0;
     while (i < n_frames) {
         const uint32_t group = pipelined ? n_frames : 1u;
@@ -1401,10 +1449,17 @@ int rt_dispatch_frames_static(rt_context *ctx, RtUniform *uniform, uint32_t n_fr
         uniform->frame += group - 1;
         i += group;
     }
-    RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->timed = true;
+    if (!capturing) {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+        RT_HIP(hipEventRecord(g_scratch_done[ctx->device], ctx->stream));
+        g_scratch_used[ctx->device] = true;
+        ctx->timed = true;
+    }
     return RT_OK;
 }
+
+uint64_t rt_debug_alloc_count(void) { return g_device_allocs.load(); }
 
 int rt_sync(rt_context *ctx) {
     if (!ctx) return fail(RT_ERR_INVALID_ARGUMENT, "ctx is null");
@@ -1433,7 +1488,7 @@ int rt_capture_rgb8(rt_context *ctx, uint8_t *dst) {
         RT_HIP(hipStreamSynchronize(ctx->stream));
         dev_free(ctx->d_rgb);
         ctx->rgb_bytes = 0;
-        RT_HIP(hipMalloc((void **)&ctx->d_rgb, n_pixels * 3));
+        RT_HIP(dev_malloc((void **)&ctx->d_rgb, n_pixels * 3));
         ctx->rgb_bytes = n_pixels * 3;
     }
     hipError_t e = rt_launch_capture(ctx->d_accum, ctx->d_rgb, n_pixels, ctx->stream);
@@ -1477,6 +1532,7 @@ int rt_stats(rt_context *ctx, RtStats *out) {
     out->launches = ctx->launches;
     out->stack_entries = ctx->stack_entries;
     out->resident_blocks = (uint32_t)ctx->persistent_blocks;
+    out->node_format = !ctx->have_scene ? 0u : (ctx->node_wide ? (ctx->node_compact ? 4u : 3u) : (ctx->node_q8 ? 2u : 1u));
     return RT_OK;
 }
 
@@ -1536,6 +1592,7 @@ int rt_host_scene_finish(const rt_host_scene *s, rt_context *ctx) {
 struct rt_group {
     std::vector<rt_context *> ctx;
     std::vector<hipEvent_t> done;      // per shard: its stream's work up to the gather
+    std::vector<int> peer;             // per shard: how its bands reach device 0 (rt_group_peer_access)
     float *d_gather = nullptr;         // on ctx[0]'s device: all shards' packed rows, one shard after the other
     float *d_image = nullptr;          // on ctx[0]'s device: the de-interleaved image
     uint64_t image_elems = 0;
@@ -1604,14 +1661,19 @@ int rt_group_create(const int *device_ids, int n_devices, rt_group **out) {
         g->ctx.push_back(c);
         g->done.push_back(ev);
     }
-    // peer access lets the gather's copies go GPU to GPU over xGMI; without it HIP stages them through the host
+    // peer access lets the gather's copies go GPU to GPU over xGMI; without it HIP stages them through the host.  The outcome
+    // per shard is kept for rt_group_peer_access: a host-staged gather still gives the right image, only slower — the caller
+    // (bench.py --mode group prints it) must be able to see which one it got.
+    g->peer.assign((size_t)n_devices, RT_PEER_SAME_DEVICE);
     for (int i = 1; i < n_devices; i++) {
         if (device_ids[i] == device_ids[0]) continue;
         int can = 0;
+        g->peer[(size_t)i] = RT_PEER_UNAVAILABLE;
         if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) {
             (void)hipSetDevice(device_ids[0]);
-            (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
-            (void)hipGetLastError();               // "already enabled" is fine
+            const hipError_t e = hipDeviceEnablePeerAccess(device_ids[i], 0);
+            (void)hipGetLastError();               // clears the sticky "already enabled"
+            g->peer[(size_t)i] = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? RT_PEER_ENABLED : RT_PEER_ENABLE_FAILED;
         }
     }
     *out = g;
@@ -1635,6 +1697,12 @@ int rt_group_destroy(rt_group *g) {
 }
 
 int rt_group_size(const rt_group *g) { return g ? (int)g->ctx.size() : 0; }
+
+int rt_group_peer_access(const rt_group *g, int *status, int n) {
+    if (!g || !status || n < (int)g->ctx.size()) return fail(RT_ERR_INVALID_ARGUMENT, "rt_group_peer_access: room for %d entries needed", g ? (int)g->ctx.size() : 0);
+    for (size_t i = 0; i < g->ctx.size(); i++) status[i] = g->peer[i];
+    return RT_OK;
+}
 
 int rt_group_context(rt_group *g, int shard, rt_context **out) {
     if (!g || !out || shard < 0 || shard >= (int)g->ctx.size()) return fail(RT_ERR_INVALID_ARGUMENT, "shard out of range");
@@ -1696,18 +1764,17 @@ int rt_group_models_update(rt_group *g, const RtGpuModel *models, uint32_t n_mod
     if (!c0->have_scene) return fail(RT_ERR_NO_SCENE, "rt_group_models_update before rt_group_scene_upload");
     // the first context takes the update exactly as rt_models_update does (it validates, and commits the shared host copy);
     // the others then follow the path it took: a refit on their own device, or the upload of what the host rebuilt
-    const uint64_t refits_before = c0->refits;
-    const bool device_path_possible = c0->opt_refit == 2 && c0->d_parent != nullptr;
-    int r = rt_models_update(c0, models, n_models, transforms);
+    Built b;                                                 // filled when the update took a host build (refit or rebuild): ONE, shared
+    int r = models_update_impl(c0, models, n_models, transforms, &b);
     if (r) return r;
-    const bool refitted_on_device = device_path_possible && c0->refits == refits_before + 1 && c0->last_update_on_device;
     if (g->ctx.size() == 1) return RT_OK;
-    if (refitted_on_device) {
-        for (size_t i = 1; i < g->ctx.size() && r == RT_OK; i++) r = device_refit(g->ctx[i]);
+    if (!b.valid) {                                          // c0 refitted on its device: so does every other device
+        for (size_t i = 1; i < g->ctx.size() && r == RT_OK; i++) {
+            Built own;
+            r = device_refit(g->ctx[i], &own);               // (same inputs, so the same path; a device that disagrees rebuilt for itself)
+        }
         return r;
     }
-    Built b;
-    r = host_build(c0, /*allow_refit=*/true, b);             // same inputs, same tree: one more host pass, shared by the other devices
     for (size_t i = 1; i < g->ctx.size() && r == RT_OK; i++) r = device_upload(g->ctx[i], b);
     return r;
 }
@@ -1724,8 +1791,8 @@ int rt_group_accum_resize(rt_group *g, uint32_t w, uint32_t h) {
         if (elems > g->image_elems) {
             dev_free(g->d_gather); dev_free(g->d_image);
             g->image_elems = 0;
-            RT_HIP(hipMalloc((void **)&g->d_gather, elems * sizeof(float)));
-            RT_HIP(hipMalloc((void **)&g->d_image, elems * sizeof(float)));
+            RT_HIP(dev_malloc((void **)&g->d_gather, elems * sizeof(float)));
+            RT_HIP(dev_malloc((void **)&g->d_image, elems * sizeof(float)));
             g->image_elems = elems;
         }
     }
@@ -1783,7 +1850,7 @@ int rt_group_capture_rgb8(rt_group *g, uint8_t *dst) {
         RT_HIP(hipStreamSynchronize(c0->stream));
         dev_free(c0->d_rgb);
         c0->rgb_bytes = 0;
-        RT_HIP(hipMalloc((void **)&c0->d_rgb, n_pixels * 3));
+        RT_HIP(dev_malloc((void **)&c0->d_rgb, n_pixels * 3));
         c0->rgb_bytes = n_pixels * 3;
     }
     RT_HIP(rt_launch_capture(image, c0->d_rgb, n_pixels, c0->stream));

@@ -38,7 +38,9 @@
 // rt_render_persistent<false, false, true> on 8-ary nodes (found by tests/checkers/fuzz_parity.py).
 // The phased kernel has no divergent loop at all — every loop in it exits on a wave-uniform condition — and is the only
 // code that gets the flag.  With neither macro (tools/kernel_regs.sh, tools/isa_bodies.py) the file is one unit.
-#if !defined(RT_TU_PHASED) && !defined(RT_TU_SIMPLE)
+// -DRT_TU_DEVICE_ONLY (tools/exp_ray_order/): the device functions and kernel templates alone, no launcher — for a developer
+// unit that includes this file to instantiate kernels of its own.
+#if !defined(RT_TU_PHASED) && !defined(RT_TU_SIMPLE) && !defined(RT_TU_DEVICE_ONLY)
 #define RT_TU_PHASED 1
 #define RT_TU_SIMPLE 1
 #endif
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(kBlock) void rt_render_persistent(const RenderParam
 
 #endif  // RT_TU_SIMPLE
 
-#ifdef RT_TU_PHASED
+#if defined(RT_TU_PHASED) || defined(RT_TU_DEVICE_ONLY)
 // ---- variant 2: persistent wavefronts, lanes scheduled by phase ----
 // Ray lengths differ wildly inside a wave (a sky ray visits 3 nodes, a ray through
 // the teapot 80), so a wave that traces "one ray per lane" waits for its slowest
@@ -789,7 +791,10 @@ enum : int { PH_NODE = 0, PH_LEAF = 1, PH_SHADE = 2, PH_FETCH = 4, PH_DONE = 5 }
 constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel-frame that has not started its first path
 
 // FMT: node format — 0 = 48-byte binary nodes, 1 = 32-byte binary nodes (q8), 2 = 80-byte 8-ary nodes (DevNode8), 3 = 64-byte 8-ary nodes (DevNode8c)
-template <bool COUNT, bool AOV, bool SPH, bool LDSM, int FMT>
+// RAYLIST (developer instances, tools/exp_ray_order/): the same scheduler and traversal over a LIST of rays instead of pixels — FETCH
+// takes ray P.aov[q] (or q when P.aov is null) of the P.stage_stride rays in P.stage (origin, direction: two float4 each) and SHADE
+// only stores the committed hit (t bits, slot) to ((uint2 *)P.accum)[ray]: what a wavefront tracer's trace pass would run.
+template <bool COUNT, bool AOV, bool SPH, bool LDSM, int FMT, bool RAYLIST = false>
 __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
     constexpr bool Q8 = FMT == 1, WIDE = FMT >= 2, COMPACT = FMT == 3;
     constexpr int kPrioNode = WIDE ? RT_PRIO_NODE_WIDE : RT_PRIO_NODE_BINARY, kPrioLeaf = WIDE ? RT_PRIO_LEAF_WIDE : RT_PRIO_LEAF_BINARY;
@@ -802,7 +807,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
     }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t frame_slots = P.tiles_x * P.local_bands * 64u;
-    const uint32_t total_slots = frame_slots * P.n_frames;    // work items: frame-major (host keeps this below 2^32)
+    const uint32_t total_slots = RAYLIST ? (uint32_t)P.stage_stride : frame_slots * P.n_frames;    // work items: frame-major (host keeps this below 2^32)
     const Camera C = load_camera(P);
     const bool cull = (P.flags & 1u) != 0;
     const bool cw = P.front_face_cw != 0;
@@ -1053,6 +1058,13 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
         } else if (pick == PH_SHADE) {
             // hit or miss shading (main.wgsl:46-69); a path that ends starts the pixel's next sample or moves on to FETCH
             do {
+            if (RAYLIST) {
+                if (phase == PH_SHADE) {
+                    tl.rays++;
+                    reinterpret_cast<uint2 *>(P.accum)[S.xf] = make_uint2(__float_as_uint(best.t), best.slot);
+                    phase = PH_FETCH;
+                }
+            } else
             if (phase == PH_SHADE) {
                 if (COUNT && first_active_lane()) tl.w_steps++;
                 // a lane comes here with a traced ray to shade, or (bounce == kFreshPixel) straight from FETCH with a
@@ -1114,6 +1126,17 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
             } else {
                 const uint32_t take = min(w_end - w_next, (uint32_t)c_free);
                 const uint32_t rank = (uint32_t)__popcll(m_free & ((1ull << lane) - 1ull));
+                if (RAYLIST) {
+                    if (phase == PH_FETCH && rank < take) {
+                        const uint32_t q = w_next + rank;
+                        const uint32_t r = P.aov ? P.aov[q] : q;
+                        const float4 ro = P.stage[2u * (size_t)r], rd = P.stage[2u * (size_t)r + 1u];
+                        S.pos = v3(ro.x, ro.y, ro.z);
+                        S.dir = v3(rd.x, rd.y, rd.z);
+                        S.xf = r;
+                        start_trace();
+                    }
+                } else
                 if (phase == PH_FETCH && rank < take) {
                     uint32_t q = w_next + rank, f = 0;
                     if (P.n_frames > 1u) { f = q / frame_slots; q -= f * frame_slots; }
@@ -1155,7 +1178,7 @@ __global__ __launch_bounds__(256) void rt_blend_frames(const RenderParams P, siz
     *dst = make_float4(acc.x, acc.y, acc.z, old.w);
 }
 
-#endif  // RT_TU_PHASED
+#endif  // RT_TU_PHASED || RT_TU_DEVICE_ONLY
 
 #ifdef RT_TU_SIMPLE
 // ---- variant 1: one wave per 8x8 tile (the reference's mapping) ----

@@ -26,7 +26,7 @@ int main(int argc, char **argv) {
     RtUniform u;
     rt_host_uniform_default(&u);               // src/main.rs:73-84
     uint32_t w = 256, h = 256, frames = 1;
-    int device = 0;
+    int device = 0, node_format = 0;
     std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -45,6 +45,7 @@ int main(int argc, char **argv) {
         else if (a == "--environment") u.environment = (float)atof(next());
         else if (a == "--cull-backfaces") u.flags |= RT_FLAG_CULL_BACKFACES;
         else if (a == "--device") device = atoi(next());
+        else if (a == "--node-format") node_format = atoi(next());       // RT_OPT_NODE_FORMAT (0 = by scene size)
         else if (a == "--devices") { for (const char *p = next(); *p;) { devices.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; } }
         else { fprintf(stderr, "rt_cli: unknown argument %s\n", a.c_str()); return 2; }
     }
@@ -59,6 +60,7 @@ int main(int argc, char **argv) {
         const rt_host_scene *s = hs;
         rt_group *g = nullptr;
         if (rt_group_create(devices.data(), (int)devices.size(), &g)) return die("group create");
+        if (node_format && rt_group_set_option(g, RT_OPT_NODE_FORMAT, node_format)) return die("node format");
         if (rt_group_scene_upload(g, rt_host_scene_vertices(s), rt_host_scene_vertex_count(s), rt_host_scene_indices(s), rt_host_scene_index_count(s),
                                   rt_host_scene_primitives(s), rt_host_scene_model_count(s), nullptr, rt_host_scene_models(s), rt_host_scene_model_count(s)))
             return die("group scene upload");
@@ -85,6 +87,7 @@ int main(int argc, char **argv) {
     }
     rt_context *ctx = nullptr;
     if (rt_create(device, &ctx)) return die("create");
+    if (node_format && rt_set_option(ctx, RT_OPT_NODE_FORMAT, node_format)) return die("node format");
     if (rt_host_scene_finish(hs, ctx)) return die("scene upload");       // ≙ scene.finish(&gpu), src/main.rs:39
     if (rt_accum_resize(ctx, w, h)) return die("accum");                 // ≙ src/app.rs:87-93
     if (rt_dispatch_frames(ctx, &u, frames)) return die("dispatch");     // ≙ src/app.rs:78-101, `frames` times

@@ -375,7 +375,8 @@ def test_headless_cli_capture_matches_oracle(rt, oracle_mod, oracle_scenes, tmp_
     pos = ",".join(str(v) for v in cfg["position"])
     r = subprocess.run([exe, "--scene", scene_path("cornell-box"), "--size", f"{w}x{h}", "--samples", str(spp), "--frames", str(frames),
                         "--bounces", str(cfg["max_bounces"]), "--pos", pos, "--yaw", repr(cfg["yaw"]), "--pitch", "0", "--out", out]
-                       + (["--devices", devices] if devices else []),
+                       + (["--devices", devices] if devices else [])
+                       + (["--node-format", os.environ["RT_AMD_NODE_FORMAT"]] if os.environ.get("RT_AMD_NODE_FORMAT") else []),   # the 8-ary child runs
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     accum, _ = oracle_scenes("cornell-box").render_frames(uniforms_for(oracle_mod, cfg, w, h, samples=spp), frames, mode=1)

@@ -1,0 +1,133 @@
+// calibrate.hip — what do the PMC counters behind bench.py's roofline count, and what are the peaks they are compared with?
+//   Every dispatch here has a KNOWN number of wave-instructions / lane-loads; run once plain for the
+// times and once per `rocprofv3 --pmc` pass for the counters, then tools/calibration_summary.py joins the two by dispatch order.
+//
+//   VALU: INDEPENDENT instruction streams (16 accumulators per lane, no dependence between neighbouring instructions), 6 waves per
+//         SIMD resident (256 CUs x 6 workgroups of 256), one instruction kind per dispatch -> clocks per wave64 instruction per
+//         SIMD at full occupancy = the issue peak SQ_INSTS_VALU / clock has to be compared with.
+//   L1:   every lane gathers 16 bytes from its own random 64-byte line of an 8 KB (L1-resident) or 2 MB (L2-resident) table, or
+//         all lanes of a quad / of the wave share a line -> TCP_TOTAL_CACHE_ACCESSES per lane-load and the lane-loads per clock.
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/microbench/calibrate.hip -o tools/microbench/calibrate.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+enum Kind { FMA, FMA_MIX, MAX3, CVT_UBYTE, ALIGNBIT, CNDMASK, MUL_LO_U32, RCP, SQRT, ADD_U32 };
+static const char *kind_name[] = {"v_fma_f32", "v_fma_mix_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_alignbit_b32", "v_cndmask_b32", "v_mul_lo_u32", "v_rcp_f32", "v_sqrt_f32", "v_add_u32"};
+
+template <int K>
+__device__ __forceinline__ void op(float &a, float b, float c) {
+    if (K == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == FMA_MIX) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a) : "v"(b), "v"(c));
+    if (K == MAX3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == CVT_UBYTE) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "+v"(a) : "v"(b));
+    if (K == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(b));
+    if (K == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == RCP) asm volatile("v_rcp_f32 %0, %1" : "+v"(a) : "v"(b));
+    if (K == SQRT) asm volatile("v_sqrt_f32 %0, %1" : "+v"(a) : "v"(b));
+    if (K == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+}
+
+// 16 independent accumulators x 4 rounds = 64 VALU instructions per loop iteration, nothing else vector in the loop
+template <int K>
+__global__ __launch_bounds__(256) void valu_stream(int iters, float *out) {
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = (float)(threadIdx.x + k);
+    const float b = 1.0001f, c = 0.5f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) op<K>(acc[k], b, c);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += acc[k];
+    if (s == 123.456f) out[0] = s;
+}
+
+// share = 1: every lane its own line; 4: the lanes of a quad share a line (and an address); 64: the whole wave one address
+template <int SHARE>
+__global__ __launch_bounds__(256) void gather16(const float *__restrict__ table, uint32_t mask_lines, int iters, float *out) {
+    uint32_t s = ((blockIdx.x * 256u + threadIdx.x) / SHARE) * 2654435761u + 12345u;
+    float acc = 0.0f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            s = s * 747796405u + 2891336453u;
+            const float4 v = *reinterpret_cast<const float4 *>(table + ((s >> 8) & mask_lines) * 16u);
+            acc += v.x + v.y + v.z + v.w;
+        }
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+int main() {
+    float *out;
+    CHECK(hipMalloc((void **)&out, 4));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    int cus = 0, clock_khz = 0;
+    CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    CHECK(hipDeviceGetAttribute(&clock_khz, hipDeviceAttributeClockRate, 0));
+    const double clk = clock_khz * 1e3;
+    printf("# device: %d CUs, %.2f GHz (hipDeviceAttributeClockRate); dispatch index | what | known count | ms | derived\n", cus, clk / 1e9);
+    int dispatch = 0;
+    const int blocks = cus * 6, iters = 4000;          // 6 waves per SIMD resident, one round: every wave lives for the whole dispatch
+    auto time_valu = [&](int kind, auto kernel) {
+        for (int rep = 0; rep < 2; rep++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, iters, out);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double wave_insts = (double)blocks * 4 * iters * 64;
+            printf("%d | valu %s rep %d | wave_insts %.0f | %.4f ms | %.3f clocks per wave64 instruction per SIMD, %.3f insts per clock per SIMD\n", dispatch++, kind_name[kind], rep,
+                   wave_insts, ms, ms * 1e-3 * clk / (wave_insts / (cus * 4.0)), (wave_insts / (cus * 4.0)) / (ms * 1e-3 * clk));
+        }
+    };
+    time_valu(FMA, valu_stream<FMA>);
+    time_valu(FMA_MIX, valu_stream<FMA_MIX>);
+    time_valu(MAX3, valu_stream<MAX3>);
+    time_valu(CVT_UBYTE, valu_stream<CVT_UBYTE>);
+    time_valu(ALIGNBIT, valu_stream<ALIGNBIT>);
+    time_valu(CNDMASK, valu_stream<CNDMASK>);
+    time_valu(MUL_LO_U32, valu_stream<MUL_LO_U32>);
+    time_valu(RCP, valu_stream<RCP>);
+    time_valu(SQRT, valu_stream<SQRT>);
+    time_valu(ADD_U32, valu_stream<ADD_U32>);
+
+    const int gblocks = cus * 8, giters = 2000;
+    for (uint32_t lines : {128u, 32768u}) {               // 8 KB (L1-resident) and 2 MB (L2-resident)
+        std::vector<float> h(lines * 16, 1.0f);
+        float *d;
+        CHECK(hipMalloc((void **)&d, lines * 64));
+        CHECK(hipMemcpy(d, h.data(), lines * 64, hipMemcpyHostToDevice));
+        auto time_gather = [&](int share, auto kernel) {
+            for (int rep = 0; rep < 2; rep++) {
+                CHECK(hipEventRecord(e0));
+                hipLaunchKernelGGL(kernel, dim3(gblocks), dim3(256), 0, 0, d, lines - 1, giters, out);
+                CHECK(hipEventRecord(e1));
+                CHECK(hipEventSynchronize(e1));
+                float ms;
+                CHECK(hipEventElapsedTime(&ms, e0, e1));
+                const double lane_loads = (double)gblocks * 256 * giters * 4;
+                printf("%d | gather 16 B, table %u KB, %d lanes per line, rep %d | lane_loads %.0f | %.4f ms | %.3f lane-loads per clock per CU, %.3f wave-loads per clock per CU\n", dispatch++,
+                       lines * 64 / 1024, share, rep, lane_loads, ms, lane_loads / (ms * 1e-3 * clk) / cus, lane_loads / 64 / (ms * 1e-3 * clk) / cus);
+            }
+        };
+        time_gather(1, gather16<1>);
+        time_gather(4, gather16<4>);
+        time_gather(64, gather16<64>);
+        CHECK(hipFree(d));
+    }
+    return 0;
+}
