@@ -366,6 +366,10 @@ int rt_group_accum_resize(rt_group *g, uint32_t w, uint32_t h);
 int rt_group_dispatch(rt_group *g, const RtUniform *uniform);
 int rt_group_dispatch_frames(rt_group *g, RtUniform *uniform, uint32_t n_frames);
 int rt_group_sync(rt_group *g);
+/* The same gather without the copy to the host: renders finished, bands gathered and de-interleaved on device_ids[0], and
+ * *device_image = the w x h x 16-byte image THERE (owned by the group, valid until the next gather / resize / destroy).
+ * What a host that keeps the image on the GPU (present pass, encoder) calls; also what bench.py --mode group times. */
+int rt_group_accum_gather(rt_group *g, void **device_image);
 int rt_group_accum_download(rt_group *g, float *dst);
 int rt_group_capture_rgb8(rt_group *g, uint8_t *dst);
 int rt_group_stats(rt_group *g, RtStats *out);

@@ -16,7 +16,8 @@ from . import obj_loader
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_lib = None
+_ALT_LIB_PATH = os.path.join(_HERE, "liboracle_alt.so")     # the same source under -DORACLE_ALT_MATH (rt_oracle.c header)
+_libs = {}
 
 UNIFORM_DTYPE = np.dtype(
     {"names": ["window", "position", "pitch", "yaw", "fov", "aspect", "frame", "accumulation_frame",
@@ -34,17 +35,18 @@ class Counters(C.Structure):
 def build(force: bool = False) -> str:
     """Compile rt_oracle.c → liboracle.so (gcc; RTN-1 flags)."""
     src = os.path.join(_HERE, "rt_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    if force or any(not os.path.exists(p) or os.path.getmtime(p) < os.path.getmtime(src) for p in (_LIB_PATH, _ALT_LIB_PATH)):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+def lib(alt: bool = False):
+    """liboracle.so (the RTN-1 contract: the checker of bits) or, alt=True, liboracle_alt.so (the tolerance yardstick)."""
+    if alt not in _libs:
+        path = _ALT_LIB_PATH if alt else _LIB_PATH
+        if not os.path.exists(path):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path)
         L.oracle_scene_create.restype = C.c_void_p
         L.oracle_scene_create.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32,
                                           C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int]
@@ -71,8 +73,12 @@ def lib():
         L.oracle_seed.argtypes = [C.c_uint32, C.c_uint32]
         L.oracle_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.oracle_capture_rgb8.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
-        _lib = L
-    return _lib
+        L.oracle_render_rect_hash.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_int, C.c_void_p]
+        L.oracle_variant.restype = C.c_int
+        assert L.oracle_variant() == (1 if alt else 0)
+        _libs[alt] = L
+    return _libs[alt]
 
 
 def make_uniform(width, height, position, yaw, pitch=0.0, fov=np.pi / 2, aspect=None, frame=1,
@@ -98,15 +104,16 @@ def make_uniform(width, height, position, yaw, pitch=0.0, fov=np.pi / 2, aspect=
 class OracleScene:
     """Holds numpy scene arrays alive and the C-side triangle list / BVH."""
 
-    def __init__(self, scene: obj_loader.Scene, transforms=None, spheres=None, build_bvh=True):
+    def __init__(self, scene: obj_loader.Scene, transforms=None, spheres=None, build_bvh=True, alt=False):
         self.scene = scene
+        self.alt = alt
         self.vertices = np.ascontiguousarray(scene.vertices)
         self.indices = np.ascontiguousarray(scene.indices, dtype=np.uint32)
         self.primitives = np.ascontiguousarray(scene.primitives)
         self.models = np.ascontiguousarray(scene.models)
         self.transforms = None if transforms is None else np.ascontiguousarray(transforms, dtype=np.float32)
         self.spheres = None if spheres is None else np.ascontiguousarray(spheres)
-        L = lib()
+        L = lib(alt)
         self.handle = L.oracle_scene_create(
             self.vertices.ctypes.data, len(self.vertices), self.indices.ctypes.data, len(self.indices),
             self.primitives.ctypes.data, len(self.primitives),
@@ -125,20 +132,21 @@ class OracleScene:
 
     def __del__(self):
         if getattr(self, "handle", None):
-            lib().oracle_scene_destroy(self.handle)
+            lib(self.alt).oracle_scene_destroy(self.handle)
             self.handle = None
 
     @property
     def n_triangles(self):
-        return lib().oracle_scene_triangles(self.handle)
+        return lib(self.alt).oracle_scene_triangles(self.handle)
 
     @property
     def n_nodes(self):
-        return lib().oracle_scene_nodes(self.handle)
+        return lib(self.alt).oracle_scene_nodes(self.handle)
 
-    def render(self, uniform, accum=None, mode=1, rows=None, want_hits=False, cols=None):
+    def render(self, uniform, accum=None, mode=1, rows=None, want_hits=False, cols=None, path_hash=None):
         """One dispatch (shaders/main.wgsl:14-33) into `accum` ([H, W, 4] f32, updated in place); rows / cols restrict it to a
-        rectangle of pixels (the others keep their values)."""
+        rectangle of pixels (the others keep their values).  path_hash: [H, W] uint32 array that receives a hash of the hit ids
+        of all rays of each pixel-frame (which pixels took the same paths in two renders)."""
         u = np.ascontiguousarray(uniform)
         W, H = int(u["window"][0][0]), int(u["window"][0][1])
         if accum is None:
@@ -148,8 +156,10 @@ class OracleScene:
         cnt = Counters()
         y0, y1 = rows if rows is not None else (0, H)
         x0, x1 = cols if cols is not None else (0, W)
-        lib().oracle_render_rect(self.handle, u.ctypes.data, accum.ctypes.data,
-                                 None if hits is None else hits.ctypes.data, x0, x1, y0, y1, mode, C.byref(cnt))
+        if path_hash is not None:
+            assert path_hash.shape == (H, W) and path_hash.dtype == np.uint32 and path_hash.flags.c_contiguous
+        lib(self.alt).oracle_render_rect_hash(self.handle, u.ctypes.data, accum.ctypes.data, None if hits is None else hits.ctypes.data,
+                                              None if path_hash is None else path_hash.ctypes.data, x0, x1, y0, y1, mode, C.byref(cnt))
         return accum, hits, cnt
 
     def render_frames(self, uniform, n_frames, mode=1):
@@ -171,14 +181,14 @@ class OracleScene:
         d = np.asarray(direction, np.float32)
         out = np.zeros(3, np.float32)
         ids = np.zeros(3, np.uint32)
-        hit = lib().oracle_trace(self.handle, o.ctypes.data, d.ctypes.data, int(cull), mode,
+        hit = lib(self.alt).oracle_trace(self.handle, o.ctypes.data, d.ctypes.data, int(cull), mode,
                                  out.ctypes.data, ids.ctypes.data)
         return (bool(hit), out, ids)
 
     def second_nearest(self, origin, direction, geometry, primitive, cull=False):
         o = np.asarray(origin, np.float32)
         d = np.asarray(direction, np.float32)
-        return float(lib().oracle_second_nearest(self.handle, o.ctypes.data, d.ctypes.data, int(cull),
+        return float(lib(self.alt).oracle_second_nearest(self.handle, o.ctypes.data, d.ctypes.data, int(cull),
                                                  int(geometry), int(primitive)))
 
 

@@ -22,6 +22,13 @@
  * (shaders/main.wgsl:79-83) and has no reference code: the ground truth here
  * is brute force over all triangles; a SAH BVH2 gives the same hits faster
  * and counts node visits / triangle tests for the byte model.
+ *
+ * -DORACLE_ALT_MATH (liboracle_alt.so; tests/golden/make_tolerance.py): the same algorithm with the arithmetic
+ * freedoms WGSL / Vulkan leave a real driver taken the OTHER way — libm sinf / cosf / tanf / powf instead of the
+ * contract's polynomials and multiplies, normalize by division, Moller-Trumbore and the sphere quadratic as plain
+ * expressions, and the whole file compiled with -ffp-contract=fast (the compiler fuses multiply-adds where it
+ * likes).  It is the yardstick for the north_star's radiance tolerance: how far a different but legal
+ * implementation of shaders/ray.wgsl:6,55-58 and main.wgsl:79-83,107 moves the image and the hit ids.
  */
 #include <math.h>
 #include <stdint.h>
@@ -111,8 +118,13 @@ static inline v3 cross(v3 a, v3 b) {
 }
 /* WGSL normalize(v) = v / length(v); RTN-1: one reciprocal, three multiplies */
 static inline v3 normalize(v3 a) {
+#ifdef ORACLE_ALT_MATH
+    float len = sqrtf(dot(a, a));
+    return V(a.x / len, a.y / len, a.z / len);
+#else
     float inv = 1.0f / sqrtf(dot(a, a));
     return scale(a, inv);
+#endif
 }
 /* WGSL mix(a, b, t) = a*(1-t) + b*t */
 static inline v3 mix3(v3 a, v3 b, float t) { return add(scale(a, 1.0f - t), scale(b, t)); }
@@ -133,6 +145,11 @@ static inline v3 face_forward(v3 e1, v3 e2, v3 e3) { return dot(e2, e3) < 0.0f ?
  * classic single-precision minimax polynomials on [-pi/4, pi/4].  Accurate to
  * about 1 ulp for |x| < 1e4, far inside Vulkan's 2^-11 absolute allowance. */
 void oracle_sincos(float x, float *s_out, float *c_out) {
+#ifdef ORACLE_ALT_MATH
+    *s_out = sinf(x);
+    *c_out = cosf(x);
+    return;
+#endif
     float kf = floorf(x * 0.63661977236758134308f + 0.5f);
     float r = fmaf(kf, -1.5703125f, x);
     r = fmaf(kf, -4.837512969970703125e-4f, r);
@@ -151,7 +168,11 @@ void oracle_sincos(float x, float *s_out, float *c_out) {
 }
 static inline float o_sin(float x) { float s, c; oracle_sincos(x, &s, &c); return s; }
 static inline float o_cos(float x) { float s, c; oracle_sincos(x, &s, &c); return c; }
+#ifdef ORACLE_ALT_MATH
+static inline float o_tan(float x) { return tanf(x); }
+#else
 static inline float o_tan(float x) { float s, c; oracle_sincos(x, &s, &c); return s / c; }
+#endif
 
 /* ------------------------------------------------------------------ RNG -- */
 /* shaders/random.wgsl:1-7 */
@@ -262,8 +283,12 @@ static float schlick_approximation(float cos_theta, float refractive_index) {
     float r = (1.0f - refractive_index) / (1.0f + refractive_index);
     float rs = r * r;
     float x = 1.0f - cos_theta;
+#ifdef ORACLE_ALT_MATH
+    float x5 = powf(x, 5.0f);
+#else
     float x2 = x * x;
     float x5 = (x2 * x2) * x;
+#endif
     return rs + (1.0f - rs) * x5;
 }
 /* shaders/ray.wgsl:34-49 */
@@ -286,10 +311,18 @@ static v3 scattered_direction_dielectric(uint32_t *seed, v3 dir, const OIntersec
 /* Ray/triangle test of the contract (Moller-Trumbore with explicit fmaf).
  * Replaces the driver's test behind rayQueryProceed (shaders/main.wgsl:81).
  * Returns 1 and (t,u,v,det) when origin + t*dir lies in the triangle. */
+#ifdef ORACLE_ALT_MATH
+/* plain expressions; -ffp-contract=fast decides what is fused */
+static inline float dot_fma(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cross_fma(v3 a, v3 b) { return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+#define O_FMA(a, b, c) ((a) * (b) + (c))
+#else
 static inline float dot_fma(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 static inline v3 cross_fma(v3 a, v3 b) {
     return V(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
+#define O_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
 static inline int tri_test(const OTri *tr, v3 o, v3 d, float *t, float *u, float *v, float *det_out) {
     v3 e1 = sub(tr->b, tr->a), e2 = sub(tr->c, tr->a);
     v3 p = cross_fma(d, e2);
@@ -311,8 +344,8 @@ static inline int sphere_test(const OSphere *s, v3 o, v3 d, float tmin, float tb
     v3 oc = sub(o, V(s->center[0], s->center[1], s->center[2]));
     float a = dot_fma(d, d);
     float hb = dot_fma(oc, d);
-    float c = fmaf(-s->radius, s->radius, dot_fma(oc, oc));
-    float disc = fmaf(hb, hb, -(a * c));
+    float c = O_FMA(-s->radius, s->radius, dot_fma(oc, oc));
+    float disc = O_FMA(hb, hb, -(a * c));
     if (!(disc >= 0.0f)) return 0;
     float sq = sqrtf(disc);
     float t0 = (-hb - sq) / a;
@@ -454,7 +487,7 @@ static OIntersection trace_ray(const OScene *sc, const OUniform *ctx, v3 o, v3 d
 
 /* shaders/main.wgsl:35-72 */
 static v3 sample_path(const OScene *sc, const OUniform *ctx, uint32_t *seed, float px, float py,
-                      int mode, OCounters *cnt, uint32_t *first_hit /* [2] or NULL */) {
+                      int mode, OCounters *cnt, uint32_t *first_hit /* [2] or NULL */, uint32_t *path_hash /* or NULL */) {
     float r0 = oracle_rand(seed), r1 = oracle_rand(seed);
     float offx = (r0 * 2.0f - 1.0f) / (float)ctx->window[0];
     float offy = (r1 * 2.0f - 1.0f) / (float)ctx->window[1];
@@ -467,6 +500,10 @@ static v3 sample_path(const OScene *sc, const OUniform *ctx, uint32_t *seed, flo
     for (uint32_t bounce = 0; bounce <= ctx->max_bounces; bounce++) {
         OIntersection tr = trace_ray(sc, ctx, pos, dir, mode, cnt);
         if (bounce == 0 && first_hit) { first_hit[0] = tr.geometry; first_hit[1] = tr.primitive; }
+        if (path_hash) {        /* FNV-1a over the (geometry, primitive) of every ray of the pixel-frame, in order */
+            *path_hash = (*path_hash ^ tr.geometry) * 16777619u;
+            *path_hash = (*path_hash ^ tr.primitive) * 16777619u;
+        }
         if (!tr.hit) {
             light = add(light, scale(mul(background_color(dir), color), ctx->enviroment));
             break;
@@ -508,6 +545,8 @@ static v3 tone_map(v3 x) {
  * mode 0 = brute force, 1 = BVH. */
 void oracle_render_rect(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids,
                         uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int mode, OCounters *counters);
+void oracle_render_rect_hash(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids, uint32_t *path_hash,
+                             uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int mode, OCounters *counters);
 void oracle_render_rows(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids,
                         uint32_t y0, uint32_t y1, int mode, OCounters *counters) {
     oracle_render_rect(sc, ctx, accum, hit_ids, 0, ctx->window[0], y0, y1, mode, counters);
@@ -515,6 +554,12 @@ void oracle_render_rows(const OScene *sc, const OUniform *ctx, float *accum, uin
 /* the same for pixels [x0, x1) x [y0, y1) only (brute-force checks of single pixels in big scenes) */
 void oracle_render_rect(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids,
                         uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int mode, OCounters *counters) {
+    oracle_render_rect_hash(sc, ctx, accum, hit_ids, NULL, x0, x1, y0, y1, mode, counters);
+}
+/* ... and with path_hash[W*H] (or NULL): a hash of the hit ids of ALL rays of the pixel-frame — two renders of a pixel took
+ * the same paths through the scene iff their hashes agree (tests/golden/make_tolerance.py: which pixels diverged) */
+void oracle_render_rect_hash(const OScene *sc, const OUniform *ctx, float *accum, uint32_t *hit_ids, uint32_t *path_hash,
+                             uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1, int mode, OCounters *counters) {
     uint32_t W = ctx->window[0], H = ctx->window[1];
     if (y1 > H) y1 = H;
     if (x1 > W) x1 = W;
@@ -534,7 +579,8 @@ void oracle_render_rect(const OScene *sc, const OUniform *ctx, float *accum, uin
                 v3 color = V(0.0f, 0.0f, 0.0f);
                 for (uint32_t i = 0; i < ctx->samples; i++) {
                     uint32_t *fh = (hit_ids && i == 0) ? &hit_ids[2 * (size_t)pixel_idx] : NULL;
-                    color = add(color, sample_path(sc, ctx, &seed, px, py, mode, &cnt, fh));
+                    if (path_hash && i == 0) path_hash[pixel_idx] = 2166136261u;
+                    color = add(color, sample_path(sc, ctx, &seed, px, py, mode, &cnt, fh, path_hash ? &path_hash[pixel_idx] : NULL));
                 }
                 float ns = (float)ctx->samples;
                 color = V(color.x / ns, color.y / ns, color.z / ns);
@@ -786,6 +832,14 @@ void oracle_scene_set_textures(OScene *sc, const uint8_t *const *textures, const
 }
 /* threads oracle_render_rows runs on (bench.py's cpu_baseline.cores) */
 int oracle_threads(void) { return omp_get_max_threads(); }
+/* 0 = the RTN-1 contract, 1 = the alternative arithmetic (-DORACLE_ALT_MATH) */
+int oracle_variant(void) {
+#ifdef ORACLE_ALT_MATH
+    return 1;
+#else
+    return 0;
+#endif
+}
 uint64_t oracle_scene_triangles(const OScene *sc) { return sc->n_tris; }
 uint64_t oracle_scene_nodes(const OScene *sc) { return sc->n_nodes; }
 void oracle_scene_destroy(OScene *sc) {

@@ -67,7 +67,7 @@ EXPORTS = [
     "rt_set_shard", "rt_accum_local_rows", "rt_accum_resize", "rt_accum_bind",
     "rt_dispatch", "rt_dispatch_frames", "rt_dispatch_frames_static", "rt_frames_reserve", "rt_sync", "rt_capture_rgb8",
     "rt_accum_download", "rt_aov_download", "rt_stats", "rt_stats_reset", "rt_last_dispatch_ms",
-    "rt_debug_alloc_count", "rt_group_peer_access",
+    "rt_debug_alloc_count", "rt_group_peer_access", "rt_group_accum_gather",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_context", "rt_group_set_option", "rt_group_scene_upload",
     "rt_group_spheres_upload", "rt_group_textures_upload", "rt_group_models_update", "rt_group_accum_resize", "rt_group_dispatch",
     "rt_group_dispatch_frames", "rt_group_sync", "rt_group_accum_download", "rt_group_capture_rgb8", "rt_group_stats", "rt_group_stats_reset",
@@ -182,6 +182,7 @@ def lib():
         L.rt_group_size.argtypes = [vp]
         L.rt_group_context.argtypes = [vp, i32, C.POINTER(vp)]
         L.rt_group_peer_access.argtypes = [vp, C.POINTER(C.c_int), i32]
+        L.rt_group_accum_gather.argtypes = [vp, C.POINTER(vp)]
         L.rt_debug_alloc_count.restype = u64
         L.rt_debug_alloc_count.argtypes = []
         L.rt_group_set_option.argtypes = [vp, i32, C.c_int64]
@@ -536,6 +537,12 @@ class Group:
         out = np.zeros((self.height, self.width, 4), np.float32)
         _check(lib().rt_group_accum_download(self.handle, out.ctypes.data))
         return out
+
+    def accum_gather(self):
+        """Gather on the first device without downloading; returns the device address of the whole image there."""
+        p = C.c_void_p()
+        _check(lib().rt_group_accum_gather(self.handle, C.byref(p)))
+        return p.value
 
     def capture_rgb8(self):
         out = np.zeros((self.height, self.width, 3), np.uint8)

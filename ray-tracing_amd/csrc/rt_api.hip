@@ -1825,6 +1825,18 @@ int rt_group_sync(rt_group *g) {
     return RT_OK;
 }
 
+int rt_group_accum_gather(rt_group *g, void **device_image) {
+    if (!g || !device_image) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    const float *image = nullptr;
+    int r = group_gather(g, &image);
+    if (r) return r;
+    rt_context *c0 = g->ctx[0];
+    RT_HIP(hipSetDevice(c0->device));
+    RT_HIP(hipStreamSynchronize(c0->stream));      // the gather waited for every shard's stream (events), so this is the whole group's work
+    *device_image = const_cast<float *>(image);
+    return RT_OK;
+}
+
 int rt_group_accum_download(rt_group *g, float *dst) {
     if (!g || !dst) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     const float *image = nullptr;

@@ -833,6 +833,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
     unsigned short *const mask_plane = reinterpret_cast<unsigned short *>(lds_stack + (size_t)stack_levels * kBlock);
     uint32_t w_next = 0, w_end = 0;   // the wave's claimed chunk, wave-uniform
     bool drained = false;
+    uint32_t ng_claims = 0;           // RAYLIST: chunks this wave has taken
 
     auto start_trace = [&]() {        // rayQueryInitialize, main.wgsl:80
         auto nz = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x; };
@@ -1102,6 +1103,18 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
             }
             const unsigned long long m_free = __ballot(phase == PH_FETCH);
             const int c_free = __popcll(m_free);
+            if (RAYLIST) {
+                // no shared queue: a list is worked off by rays, 135 times as many claims per unit of work as by pixel-frames, and
+                // that many atomics on ONE address serialise (first version of the experiment: 30 ms for 8 M rays in any order).
+                // Wave w takes chunks w, w + W, w + 2 W, ... of the list: the whole grid stays inside a window of W chunks.
+                if (w_next == w_end && !drained) {
+                    const uint32_t n_waves = gridDim.x * (kBlock / 64u), wave = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+                    const uint64_t base = ((uint64_t)ng_claims * n_waves + wave) * P.chunk;
+                    ng_claims++;
+                    if (base >= total_slots) drained = true;
+                    else { w_next = (uint32_t)base; w_end = (uint32_t)min(base + P.chunk, (uint64_t)total_slots); }
+                }
+            } else
             if (w_next == w_end && !drained) {
                 uint32_t base = 0;
                 // guided grain: 4 chunks per claim while plenty of work is left (coherent tiles), one chunk near
@@ -1159,7 +1172,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
         pr[0] = t_start; pr[1] = t_drain; pr[2] = wall_clock64();
     }
 #endif
-    flush_tally<COUNT>(P, tl);
+    if (!RAYLIST || COUNT) flush_tally<COUNT>(P, tl);
 }
 
 // Second half of a multi-frame launch: out = mix(old, tone_map(sum_f / samples * exposure), 1 / (accumulation_frame + f + 1)) for

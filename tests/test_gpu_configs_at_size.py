@@ -64,12 +64,19 @@ def _uniform(mod, cfg, w, h, samples):
                             max_bounces=cfg["max_bounces"], samples=samples)
 
 
-def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_wide):
+def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_wide, audit):
+    """audit = (x0, x1, y0, y1, spp): a sub-rectangle of the window rendered once more, at `spp` samples, by the oracle's BRUTE FORCE
+    (every primitive tested against every ray, no tree at all) and compared with the device's pixels and primary hit ids there.
+    The whole-window check uses the oracle's BVH mode, which is a checker that has itself lost hits before:
+    the sub-rectangle is what ties these sizes to the ground truth."""
     cfg, s = _scene(rt, name)
     n_prims = len(s.indices) // 3 + len(s.spheres)
     osc = oracle_mod.OracleScene(obj_loader.Scene(s.vertices, s.indices, s.primitives, s.models),
                                  spheres=s.spheres if len(s.spheres) else None)
     want, want_hits, cnt = osc.render(_uniform(oracle_mod, cfg, w, h, samples), mode=1, want_hits=True)
+    ax0, ax1, ay0, ay1, aspp = audit
+    brute, brute_hits, bcnt = osc.render(_uniform(oracle_mod, cfg, w, h, aspp), mode=0, want_hits=True, rows=(ay0, ay1), cols=(ax0, ax1))
+    assert bcnt.pixel_frames == (ax1 - ax0) * (ay1 - ay0) and bcnt.triangle_tests >= bcnt.rays * (n_prims - len(s.spheres))
     del osc
     with rt.Context(0) as ctx:
         ctx.scene_upload(s.vertices, s.indices, s.primitives, s.models)
@@ -80,6 +87,10 @@ def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_wide
         ctx.dispatch(_uniform(rt, cfg, w, h, samples))
         st = ctx.stats()
         got, hits = ctx.accum_download(), ctx.aov_download()
+        # the frame of the brute-force audit: the same context, a fresh (zeroed) buffer, `aspp` samples
+        ctx.accum_resize(w, h)
+        ctx.dispatch(_uniform(rt, cfg, w, h, aspp))
+        got2, hits2 = ctx.accum_download(), ctx.aov_download()
     assert st.pixel_frames == w * h
     assert st.rays == cnt.rays, (st.rays, cnt.rays)
     # the node format chosen by size (RT_OPT_NODE_FORMAT = 0): 64-byte 8-ary nodes once the binary nodes would exceed 12 MiB
@@ -87,20 +98,24 @@ def _against_oracle(rt, oracle_mod, obj_loader, name, w, h, samples, expect_wide
     assert (per_node == 64) == expect_wide, per_node
     assert np.array_equal(hits, want_hits), f"{int((hits != want_hits).any(axis=-1).sum())} primary hit ids differ"
     assert_images_identical(got, want, name)
+    # the brute-force audit of the sub-rectangle
+    assert np.array_equal(hits2[ay0:ay1, ax0:ax1], brute_hits[ay0:ay1, ax0:ax1]), "primary hit ids differ from BRUTE FORCE in the audited rectangle"
+    assert_images_identical(got2[ay0:ay1, ax0:ax1], brute[ay0:ay1, ax0:ax1], name + ": device vs brute force, audited rectangle")
+    assert (brute_hits[ay0:ay1, ax0:ax1, 0] != 0xFFFFFFFF).mean() > 0.5, "the audited rectangle should look at geometry, not at the sky"
     return st
 
 
 def test_c4_full_scene_matches_oracle(rt, oracle_mod, obj_loader, capsys):
     """C4: 1,059 baked teapots (9.99 M triangles) + 100,000 spheres, 160x90, 16 spp, 8 bounces."""
     with heartbeat(capsys, "C4 10M"):
-        st = _against_oracle(rt, oracle_mod, obj_loader, "C4", 160, 90, 16, expect_wide=True)
+        st = _against_oracle(rt, oracle_mod, obj_loader, "C4", 160, 90, 16, expect_wide=True, audit=(72, 88, 40, 49, 2))     # 16 x 9 pixels, 2 spp
     assert st.bvh_nodes > 10_090_000 // 8 and st.stack_entries >= 16        # at most 8 children per node
 
 
 def test_c5q_50m_triangles_match_oracle(rt, oracle_mod, obj_loader, capsys):
     """C5q: 5,300 baked teapots (50 M triangles, > 4 GiB of device records: the 64-bit offset paths), 96x54, 4 spp."""
     with heartbeat(capsys, "C5q 50M"):
-        st = _against_oracle(rt, oracle_mod, obj_loader, "C5q", 96, 54, 4, expect_wide=True)
+        st = _against_oracle(rt, oracle_mod, obj_loader, "C5q", 96, 54, 4, expect_wide=True, audit=(44, 52, 25, 29, 2))     # 8 x 4 pixels, 2 spp
     assert st.bvh_bytes > (4 << 30)
 
 

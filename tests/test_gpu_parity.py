@@ -403,7 +403,7 @@ def test_bench_contract_and_sharded_image(ranks):
     import sys
     env = dict(os.environ, RT_BENCH_BACKEND="gloo")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--verify",
-           "--cpu-sample", "240x135"]
+           "--cpu-sample", "240x135", "--cpu-timed", "160x90"]
     # ranks > 1: `python bench.py --gpus N` as typed — bench.py starts its own ranks (no torch.distributed.run around it)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
@@ -418,15 +418,48 @@ def test_bench_contract_and_sharded_image(ranks):
     assert m["config"]["rays"] > 3840 * 2160 * 16 * 2
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic"):
         assert key in m["roofline"]
-    assert 0.0 < m["roofline"]["frac"] <= 1.0          # measured HBM traffic against the HBM peak: a fraction that can bind
+    prov = m["roofline"]["provenance"]
+    assert len(prov["kernel_source_sha256"]) == 64 and isinstance(prov["stale"], bool)
+    if not prov["stale"]:                            # the recorded traffic is of THIS build's device sources
+        assert 0.0 < m["roofline"]["frac"] <= 1.0    # measured HBM traffic against the HBM peak: a fraction that can bind
+    else:
+        assert "stale" in m["roofline"]["achieved_is"]
     if "onchip" in m["roofline"]:
-        assert 0.0 < m["roofline"]["onchip"]["frac"] <= 1.0
+        oc = m["roofline"]["onchip"]
+        assert isinstance(oc["stale"], bool) and oc["cus"] >= 1 and oc["clock_hz"] > 1e8
+        if not oc["stale"]:                          # no clamp anywhere: a fraction above 1 would mean a peak that is not one
+            assert 0.0 < oc["frac"] <= 1.0 and 0.0 < oc["valu"]["frac"] <= 1.0
     if ranks == 1:                                   # the CPU leg runs on rank 0 at N = 1 only
         assert m["cpu_baseline"]["kind"] == "port" and m["cpu_baseline"]["value"] > 0
         assert 1 <= m["cpu_baseline"]["cores"] <= (os.cpu_count() or 1) and m["cpu_baseline"]["cpu_model"]
-        assert m["parity"]["identical"] is True and m["parity"]["rays_equal"] is True
+        assert "best of 3" in m["cpu_baseline"]["sample"] and m["cpu_baseline"]["lavapipe_probe"]["usable"] is False
+        assert m["parity"]["identical"] is True and m["parity"]["rays_equal"] is True and m["parity"]["brute_force_pixels_identical"] is True
     else:
         assert "cpu_baseline" not in m
+
+
+def test_bench_group_mode_one_process_n_shards():
+    """bench.py --mode group: ONE process, N shards behind one rt_group (here the one GPU named twice), one scene build, the
+    peer-copy gather inside the timed region, the same JSON schema; --verify: the gathered image equals the unsharded render."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RT_BENCH_GROUP_DEVICES="0,0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "group", "--steps", "2", "--warmup", "1", "--verify", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=110, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    metric = [l for l in lines if "metric" in l]
+    verify = [l for l in lines if "verify" in l]
+    assert len(metric) == 1 and len(verify) == 1 and verify[0]["identical"] is True and verify[0]["mode"] == "group"
+    m = metric[0]
+    assert m["n_gpus"] == 2 and m["steps"] == 2 and m["value"] > 0 and m["scaling"] == "strong"
+    assert m["config"]["mode"] == "group" and m["config"]["devices"] == [0, 0] and m["config"]["host_builds"] == 1
+    assert m["config"]["peer_access"] == ["same device", "same device"]
+    assert m["config"]["rays"] > 3840 * 2160 * 16 * 2
+    assert "roofline" in m and "cpu_baseline" not in m
 
 
 def test_models_update_refits_bvh(rt, oracle_mod, scenes):

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void exp_trace_plain(const RenderParams P, 
         tl.rays++;
         hits[r] = make_uint2(__float_as_uint(h.t), h.slot);
     }
-    flush_tally<COUNT>(P, tl);
+    if (COUNT) flush_tally<COUNT>(P, tl);       // (without counting: no atomics at all — 127 k waves adding to one address serialise)
 }
 
 float4 *g_rays = nullptr;

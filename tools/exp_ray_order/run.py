@@ -75,6 +75,18 @@ def main():
         ctx.scene_finish(rt.HostScene(os.path.join(ROOT, cfg["scene"])))
     print(f"[exp] scene up in {time.time() - t0:.1f} s", flush=True)
     ctx.accum_resize(W, H)
+    # the production path on the same scene in the same process, for scale: K frames in one launch
+    pu = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]),
+                         max_bounces=cfg["max_bounces"], samples=cfg["samples"])
+    pu["frame"], pu["accumulation_frame"] = 0, 1
+    ctx.dispatch_frames(pu, args.frames)
+    ctx.stats_reset()
+    ctx.accum_resize(W, H)
+    pu["frame"], pu["accumulation_frame"] = 0, 1
+    ctx.dispatch_frames(pu, args.frames)
+    prod_ms, prod_rays = ctx.last_dispatch_ms(), int(ctx.stats().rays)
+    print(f"[exp] production render, {args.frames} frames in one launch: {prod_ms:.2f} ms, {prod_rays} rays, {prod_ms * 1e6 / prod_rays:.4f} ns/ray (shading included)", flush=True)
+    ctx.accum_resize(W, H)
     u = rt.make_uniform(W, H, cfg["position"], cfg["yaw"], cfg["pitch"], aspect=np.float32(cfg["width"]) / np.float32(cfg["height"]),
                         max_bounces=cfg["max_bounces"], samples=cfg["samples"])
     slots = ((W + 7) // 8) * ((H + 7) // 8) * 64 * args.frames
@@ -106,7 +118,8 @@ def main():
     if args.pmc:
         orders = {k: orders[k] for k in ("arrival", "morton30_then_octant")}
 
-    results = {"config": args.config, "window": [W, H], "frames": args.frames, "sample": args.sample, "bounce": args.bounce, "rays": n, "runs": []}
+    results = {"config": args.config, "window": [W, H], "frames": args.frames, "sample": args.sample, "bounce": args.bounce, "rays": n,
+               "production": {"ms": prod_ms, "rays": prod_rays, "ns_per_ray": prod_ms * 1e6 / prod_rays}, "runs": []}
     ref_hits = None
     for kernel, kname in ((1, "phased"),) if args.pmc else ((0, "plain"), (1, "phased")):
         for oname, order in orders.items():

@@ -16,8 +16,8 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Kind { FMA, FMA_MIX, MAX3, CVT_UBYTE, ALIGNBIT, CNDMASK, MUL_LO_U32, RCP, SQRT, ADD_U32 };
-static const char *kind_name[] = {"v_fma_f32", "v_fma_mix_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_alignbit_b32", "v_cndmask_b32", "v_mul_lo_u32", "v_rcp_f32", "v_sqrt_f32", "v_add_u32"};
+enum Kind { FMA, FMA_MIX, MAX3, CVT_UBYTE, ALIGNBIT, CNDMASK, MUL_LO_U32, RCP, SQRT, ADD_U32, CNDMASK_S, MUL_F32, MIN_F32 };
+static const char *kind_name[] = {"v_fma_f32", "v_fma_mix_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_alignbit_b32", "v_cndmask_b32", "v_mul_lo_u32", "v_rcp_f32", "v_sqrt_f32", "v_add_u32", "v_cndmask_b32 (sgpr mask)", "v_mul_f32", "v_min_f32"};
 
 template <int K>
 __device__ __forceinline__ void op(float &a, float b, float c) {
@@ -31,6 +31,9 @@ __device__ __forceinline__ void op(float &a, float b, float c) {
     if (K == RCP) asm volatile("v_rcp_f32 %0, %1" : "+v"(a) : "v"(b));
     if (K == SQRT) asm volatile("v_sqrt_f32 %0, %1" : "+v"(a) : "v"(b));
     if (K == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == CNDMASK_S) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(0x5555555555555555ull));
+    if (K == MUL_F32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == MIN_F32) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a) : "v"(b));
 }
 
 // 16 independent accumulators x 4 rounds = 64 VALU instructions per loop iteration, nothing else vector in the loop
@@ -104,6 +107,9 @@ int main() {
     time_valu(RCP, valu_stream<RCP>);
     time_valu(SQRT, valu_stream<SQRT>);
     time_valu(ADD_U32, valu_stream<ADD_U32>);
+    time_valu(CNDMASK_S, valu_stream<CNDMASK_S>);
+    time_valu(MUL_F32, valu_stream<MUL_F32>);
+    time_valu(MIN_F32, valu_stream<MIN_F32>);
 
     const int gblocks = cus * 8, giters = 2000;
     for (uint32_t lines : {128u, 32768u}) {               // 8 KB (L1-resident) and 2 MB (L2-resident)

@@ -2,7 +2,27 @@
 """Summarise a profiles/run_profile.sh output directory: kernel stats + per-launch PMC means + derived figures.
 usage: python tools/pmc_summary.py gpurun_out/prof_<tag> [out_dir [config-key-for-profiles/traffic.json and onchip.json [frames-per-launch]]]
 The profiled command (profiles/run_profile.sh) makes every rt_render launch the same size: --steps S --warmup S."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# Calibrated peaks (profiles/r3_calibration.txt, tools/microbench/calibrate.hip: independent instruction streams, 6 waves per SIMD;
+# fully divergent 16-byte lane-loads that hit L1), in the counters' OWN units:
+VALU_PEAK_INSTS_PER_SIMD_CLK = 0.391     # SQ_INSTS_VALU per clock per SIMD of the fastest class (v_add_u32: 2.56 clocks); v_fma_f32 0.310, v_fma_mix / v_max3 / v_alignbit / v_mul_lo 0.22, v_rcp / v_sqrt 0.122
+VALU_FMA_INSTS_PER_SIMD_CLK = 0.310
+L1_PEAK_ACCESSES_PER_CU_CLK = 1.48       # TCP_TOTAL_CACHE_ACCESSES_sum per clock per CU (one per divergent lane-load, one per QUAD of lanes sharing a line)
+
+
+def source_stamp():
+    """What ties a profile to a build: sha256 over the device sources, and the git head at the time of the reduction."""
+    h = hashlib.sha256()
+    for f in ("rt_kernels.hip", "rt_device.h", "rt_pack.h", "rt_math.h"):
+        h.update(open(os.path.join(ROOT, "ray-tracing_amd", "csrc", f), "rb").read())
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
+    return {"kernel_source_sha256": h.hexdigest(), "git_head_at_reduction": head}
+
+
 src = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else None
 vals, n = {}, {}
@@ -21,12 +41,16 @@ cyc = vals.get('GRBM_GUI_ACTIVE', 0) / 8
 if cyc:
     d["derived"] = {
         "shader_clock_GHz": cyc / (avg_ms * 1e-3) / 1e9,
-        # VALU issue rate: wave64 VALU instructions per clock per SIMD.  A SIMD16 needs 4 clocks per wave64 instruction (0.25 per
-        # clock, tools/microbench/valu_exec.hip), so valu_issue_fraction = rate / 0.25; it can read a little above 1 because
-        # GRBM_GUI_ACTIVE / 8 undercounts the clocks of a kernel this long by a few percent (the shader clock it implies is
-        # below the 2.4 GHz the SQ counters ran at).  (Round 1 printed this as "valu_busy" = 1.14.)
+        # VALU issue rate: wave64 VALU instructions per clock per SIMD (SQ_INSTS_VALU counts exactly one per wave-instruction:
+        # profiles/r3_calibration.txt), against the CALIBRATED peaks of independent instruction streams at 6 waves per SIMD.
+        # No clamp: the fraction of the fastest class's peak cannot exceed 1; the fraction of the FMA peak can (a stream of
+        # two-operand integer adds issues faster than FMAs) and says how close the kernel's mix is to an all-FMA stream.
+        # (Rounds 1 and 2 divided by a nominal 0.25 — a dependent-chain figure — and got 1.14 / 1.21.)
         "valu_insts_per_simd_clk": vals['SQ_INSTS_VALU'] / 1024 / cyc,
-        "valu_issue_fraction": min(1.0, vals['SQ_INSTS_VALU'] * 4 / 1024 / cyc),
+        "valu_frac_of_peak": vals['SQ_INSTS_VALU'] / 1024 / cyc / VALU_PEAK_INSTS_PER_SIMD_CLK,
+        "valu_frac_of_fma_peak": vals['SQ_INSTS_VALU'] / 1024 / cyc / VALU_FMA_INSTS_PER_SIMD_CLK,
+        # SQ_ACTIVE_INST_VALU counts 1 per 4-clock instruction and 2 per 8-clock one (v_rcp, v_sqrt, ...): the share of 8-clock instructions
+        "valu_8clk_inst_fraction": vals['SQ_ACTIVE_INST_VALU'] / vals['SQ_INSTS_VALU'] - 1.0,
         "valu_lane_utilization": vals['SQ_THREAD_CYCLES_VALU'] / (vals['SQ_ACTIVE_INST_VALU'] * 64),
         "waves_per_simd": vals['SQ_WAVE_CYCLES'] * 4 / 1024 / cyc,
         "l2_hit_rate": vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']),
@@ -55,6 +79,7 @@ if rays and cyc:
                     "l2_requests_per_ray": vals['TCP_TCC_READ_REQ_sum'] / rays,
                     "lds_wave_insts_per_ray": vals.get('SQ_INSTS_LDS', 0) / rays}
     d["derived"]["l1_tag_lookups_per_clk_per_cu"] = vals['TCP_TOTAL_CACHE_ACCESSES_sum'] / 256 / cyc
+    d["derived"]["l1_frac_of_peak"] = vals['TCP_TOTAL_CACHE_ACCESSES_sum'] / 256 / cyc / L1_PEAK_ACCESSES_PER_CU_CLK
     d["derived"]["lds_bank_conflict_fraction"] = vals['SQ_LDS_BANK_CONFLICT'] / vals['SQ_LDS_IDX_ACTIVE'] if vals.get('SQ_LDS_IDX_ACTIVE') else None
 print(json.dumps(d, indent=1))
 if out and len(sys.argv) > 3:
@@ -68,22 +93,25 @@ if out and len(sys.argv) > 3:
                       "hbm_bytes_per_frame": (d["derived"]["hbm_read_bytes_x2"] + d["derived"]["hbm_write_bytes"]) / fpl,
                       "read_bytes_fetch_size_x2": d["derived"]["hbm_read_bytes_x2"], "write_bytes": d["derived"]["hbm_write_bytes"],
                       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; FETCH_SIZE KiB x 2 (gfx950 reads half), WRITE_SIZE KiB x 1",
-                      "profile": out}
+                      "profile": out, **source_stamp()}
     json.dump(t, open(tp, "w"), indent=1)
     if "per_ray" in d:
         # what bench.py's roofline.onchip prices the kernel with (ceilings at the kernel's own instruction counts)
         op = os.path.join(root, "profiles", "onchip.json")
         o = json.load(open(op)) if os.path.exists(op) else {}
-        o[sys.argv[3]] = {"valu_wave_insts_per_ray": d["per_ray"]["valu_wave_insts_per_ray"], "valu_clocks_per_wave_inst": 4.0,
+        o[sys.argv[3]] = {"valu_wave_insts_per_ray": d["per_ray"]["valu_wave_insts_per_ray"],
+                          "valu_insts_per_simd_clk_peak": VALU_PEAK_INSTS_PER_SIMD_CLK, "valu_insts_per_simd_clk_fma_peak": VALU_FMA_INSTS_PER_SIMD_CLK,
                           "l1_tag_lookups_per_ray": d["per_ray"]["l1_tag_lookups_per_ray"],
-                          "l1_tag_lookups_per_clk_per_cu_peak": 1.5,
+                          "l1_tag_lookups_per_clk_per_cu_peak": L1_PEAK_ACCESSES_PER_CU_CLK,
+                          "frames_per_launch": fpl,
                           "valu_lane_utilization": d["derived"]["valu_lane_utilization"],
                           "measured_l1_tag_lookups_per_clk_per_cu": d["derived"]["l1_tag_lookups_per_clk_per_cu"],
                           "measured_valu_insts_per_simd_clk": d["derived"]["valu_insts_per_simd_clk"],
                           "method": "rocprofv3 --pmc SQ_INSTS_VALU / TCP_TOTAL_CACHE_ACCESSES_sum per launch divided by the launch's exact device-side ray count; "
-                                    "peak L1 rate 1.5 tag look-ups per clock per CU from tools/microbench/gather_width.hip (fully divergent 16-byte lane-loads, L1 hits); "
-                                    "VALU: 4 clocks per wave64 instruction per SIMD16 (tools/microbench/valu_exec.hip)",
-                          "profile": out}
+                                    "peaks in the counters' own units from profiles/r3_calibration.txt (tools/microbench/calibrate.hip under the same --pmc passes): "
+                                    "1.48 TCP_TOTAL_CACHE_ACCESSES per clock per CU (fully divergent 16-byte lane-loads, L1 hits), "
+                                    "0.391 / 0.310 SQ_INSTS_VALU per clock per SIMD (independent v_add_u32 / v_fma_f32 streams, 6 waves per SIMD)",
+                          "profile": out, **source_stamp()}
         json.dump(o, open(op, "w"), indent=1)
 if out:
     os.makedirs(out, exist_ok=True)
