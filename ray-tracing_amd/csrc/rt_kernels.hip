@@ -159,8 +159,9 @@ __device__ __forceinline__ void intersect_leaf(const DevTri *__restrict__ tris, 
 // inv comes from v_rcp_f32 (1 ulp); a zero direction component is nudged to 1e-30
 // so no inf/NaN appears.  Error of t: relative 2^-22 |t| from inv and the last
 // rounding (covered by the kFarSlack factor), absolute <= 2^-24 (2|o| + |lo|) |inv|
-// from o*inv and base, covered by eps = 2^-21 max_k (|o_k| + R_k) |inv_k| with
-// R_k = max |coordinate| of the root box (RenderParams::scene_abs).
+// from o*inv and base, covered PER AXIS by pad * |inv_k|, pad = 2^-21 max_k (|o_k| + R_k),
+// R_k = max |coordinate| of the root box (RenderParams::scene_abs): entry distances are
+// lowered by it (folded into the origin term), exit distances raised (slab_pad).
 // far bound factor of the box test: covers the relative error of t (rcp 2^-23, the phased kernel's stuffed
 // inverse 2^-18, two roundings 2^-23) on both sides of the comparison
 constexpr float kFarSlack = 1.000012f;
@@ -169,16 +170,26 @@ __device__ __forceinline__ float lo16(uint32_t w) { return (float)__builtin_bit_
 __device__ __forceinline__ float hi16(uint32_t w) { return (float)__builtin_bit_cast(rt_h2, w).y; }
 __device__ __forceinline__ uint4 ld4u(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
 
+// The absolute error of one axis' slab distances, 2^-21 (|o| + R) |inv| (see above), as a pad of THAT axis alone: the box
+// tests lower the entry planes' base by pad * |inv| and raises the exit planes' by the same, pad = 2^-21 max_k (|o_k| + R_k) (one
+// number per ray: what differs between the axes is |inv|), instead of adding the largest of the three products to the far bound.  A shared pad is harmless until a ray runs nearly parallel to an axis: |d.x| = 5.6e-9 makes the x
+// pad 1,500 scene units, and as a shared pad that switched the y and z slabs off — such a ray visited every node whose x range
+// holds its origin (C4: 10,798 node visits + 26,414 primitive tests against a mean of 27 + 4.8; 19 rays of 8.1 M above 1,000
+// visits), a dependent chain of 25 ms at the end of a launch whose other 8 M rays took 3 ms (tools/exp_ray_order/run.py --per-ray).
+__device__ __forceinline__ float slab_pad(const RenderParams &P, rt_v3 o) {
+    return 4.76837158e-7f * fmaxf(fmaxf(P.scene_abs[0] + fabsf(o.x), P.scene_abs[1] + fabsf(o.y)), P.scene_abs[2] + fabsf(o.z));
+}
+
 struct Slab {
-    float ix, iy, iz, ox, oy, oz, eps;
+    float ix, iy, iz, ox, oy, oz, pad2;     // ox..: -o * inv lowered by the axis' pad; pad2: twice the pad per unit of |inv| (see slab_pad)
 };
 __device__ __forceinline__ Slab make_slab(const RenderParams &P, rt_v3 o, rt_v3 d) {
     auto nz = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e-30f, x) : x; };
     Slab s;
     s.ix = __builtin_amdgcn_rcpf(nz(d.x)); s.iy = __builtin_amdgcn_rcpf(nz(d.y)); s.iz = __builtin_amdgcn_rcpf(nz(d.z));
-    s.ox = -(o.x * s.ix); s.oy = -(o.y * s.iy); s.oz = -(o.z * s.iz);
-    s.eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(s.ix), fabsf(s.ox)), fmaf(P.scene_abs[1], fabsf(s.iy), fabsf(s.oy))),
-                                   fmaf(P.scene_abs[2], fabsf(s.iz), fabsf(s.oz)));
+    const float pad = slab_pad(P, o);
+    s.ox = fmaf(-pad, fabsf(s.ix), -(o.x * s.ix)); s.oy = fmaf(-pad, fabsf(s.iy), -(o.y * s.iy)); s.oz = fmaf(-pad, fabsf(s.iz), -(o.z * s.iz));
+    s.pad2 = pad + pad;
     return s;
 }
 // both children of one node: entry distances n0/n1, hit flags, references
@@ -187,6 +198,7 @@ __device__ __forceinline__ void test_node(const float4 *n, const Slab &sl, float
     const float4 a = ld4(n);
     const uint4 b = ld4u(n + 1);
     const float bx = fmaf(a.x, sl.ix, sl.ox), by = fmaf(a.y, sl.iy, sl.oy), bz = fmaf(a.z, sl.iz, sl.oz);
+    const float px = sl.pad2 * fabsf(sl.ix), py = sl.pad2 * fabsf(sl.iy), pz = sl.pad2 * fabsf(sl.iz);      // what an exit distance is raised by
     float t0x, t1x, t0y, t1y, t0z, t1z, s0x, s1x, s0y, s1y, s0z, s1z;
     if (q8) {
         // two-load node (rt_pack.h): 8-bit plane offsets in units of scale = 2^(e - 20), per axis [c0.lo, c1.lo, c0.hi, c1.hi]
@@ -214,11 +226,11 @@ __device__ __forceinline__ void test_node(const float4 *n, const Slab &sl, float
         s0z = fmaf(lo16(c.z), sl.iz, bz); s1z = fmaf(hi16(c.z), sl.iz, bz);
     }
     n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), kTMin));
-    const float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tbest));
+    const float f0 = fminf(fminf(fmaxf(t0x, t1x) + px, fmaxf(t0y, t1y) + py), fminf(fmaxf(t0z, t1z) + pz, tbest));
     n1 = fmaxf(fmaxf(fminf(s0x, s1x), fminf(s0y, s1y)), fmaxf(fminf(s0z, s1z), kTMin));
-    const float f1 = fminf(fminf(fmaxf(s0x, s1x), fmaxf(s0y, s1y)), fminf(fmaxf(s0z, s1z), tbest));
-    h0 = n0 <= fmaf(f0, kFarSlack, sl.eps);
-    h1 = n1 <= fmaf(f1, kFarSlack, sl.eps);
+    const float f1 = fminf(fminf(fmaxf(s0x, s1x) + px, fmaxf(s0y, s1y) + py), fminf(fmaxf(s0z, s1z) + pz, tbest));
+    h0 = n0 <= f0 * kFarSlack;
+    h1 = n1 <= f1 * kFarSlack;
 }
 
 // nearest committed hit in (kTMin, kTMax): the ray query of main.wgsl:79-83
@@ -296,15 +308,16 @@ __device__ __forceinline__ float stuffed_inverse(float dcomp) {
 
 __device__ __forceinline__ float ubyte_f(uint32_t v, int k) { return (float)((v >> (8 * k)) & 255u); }
 
-// One visit: all eight child boxes of the node at 16-byte chunk `chunk` against the ray (ix.. = stuffed inverses, ox.. =
-// -o * inv, eps: see make_slab).  Returns the hit mask over the node's present children.  Conservative like the binary
-// nodes' test: planes are rounded outward at build time, the far bound is widened by kFarSlack and eps.
+// One visit: all eight child boxes of the node at 16-byte chunk `chunk` against the ray (ix.. = stuffed inverses; ox.. =
+// -o * inv lowered by the axis' OWN pad, pad2 = twice the pad per unit of |inverse|, see slab_pad).  Returns the hit mask over the node's present children.
+// Conservative like the binary nodes' test: planes are rounded outward at build time, the far bound is widened by kFarSlack,
+// entry distances are computed from the lowered origin term and exit distances from the raised one.
 // COMPACT: the 64-byte record (DevNode8c): four fetches; the corner is three 14-bit cell indices of the scene's grid and ox.. are
 // expected in GRID space (grid_lo * inv - o * inv, see wide_origin), the plane step is cell * 2^(e - 8) per axis.
 template <bool COMPACT>
 __device__ __forceinline__ uint32_t test_node8(const RenderParams &P, const float4 *__restrict__ n, float ix, float iy, float iz, float ox, float oy, float oz,
-                                               float eps, float tbest, uint32_t &child_base, uint32_t &tri_base, uint32_t &imask, uint32_t &lmask) {
-    float sx, sy, sz, bx, by, bz;
+                                               float pad2, float tbest, uint32_t &child_base, uint32_t &tri_base, uint32_t &imask, uint32_t &lmask) {
+    float sx, sy, sz, bx, by, bz;                   // b.: base of the entry planes (the origin term comes in lowered by the axis' pad)
     uint4 qx, qy, qz;
     if (COMPACT) {
         const uint4 hd = ld4u(n);
@@ -337,6 +350,8 @@ __device__ __forceinline__ uint32_t test_node8(const RenderParams &P, const floa
         child_base = b.x;
         tri_base = b.y;
     }
+    // base of the exit planes: the entry base raised by twice the axis' pad (one FMA per axis; |.| is an operand modifier)
+    const float cx = fmaf(pad2, fabsf(ix), bx), cy = fmaf(pad2, fabsf(iy), by), cz = fmaf(pad2, fabsf(iz), bz);
     const uint32_t rx = __float_as_uint(ix), ry = __float_as_uint(iy), rz = __float_as_uint(iz);
     const uint32_t QX[4] = {qx.x, qx.y, qx.z, qx.w}, QY[4] = {qy.x, qy.y, qy.z, qy.w}, QZ[4] = {qz.x, qz.y, qz.z, qz.w};
     uint32_t h = 0;
@@ -350,8 +365,8 @@ __device__ __forceinline__ uint32_t test_node8(const RenderParams &P, const floa
 #pragma unroll
         for (int j = 1; j >= 0; j--) {
             const float tn = fmaxf(fmaxf(fmaf(ubyte_f(px, j), sx, bx), fmaf(ubyte_f(py, j), sy, by)), fmaxf(fmaf(ubyte_f(pz, j), sz, bz), kTMin));
-            const float tf = fminf(fminf(fmaf(ubyte_f(px, 2 + j), sx, bx), fmaf(ubyte_f(py, 2 + j), sy, by)), fminf(fmaf(ubyte_f(pz, 2 + j), sz, bz), tbest));
-            const float lim = fmaf(tf, kFarSlack, eps);
+            const float tf = fminf(fminf(fmaf(ubyte_f(px, 2 + j), sx, cx), fmaf(ubyte_f(py, 2 + j), sy, cy)), fminf(fmaf(ubyte_f(pz, 2 + j), sz, cz), tbest));
+            const float lim = tf * kFarSlack;
             asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(tn), "v"(lim) : "vcc");
         }
     }
@@ -360,7 +375,6 @@ __device__ __forceinline__ uint32_t test_node8(const RenderParams &P, const floa
 
 // -o * inv, or for the compact record the same in the corner grid's space: grid_lo * inv - o * inv
 __device__ __forceinline__ float wide_origin(bool compact, float grid_lo, float o, float inv) { return compact ? fmaf(grid_lo, inv, -(o * inv)) : -(o * inv); }
-
 // nearest committed hit through the 8-ary tree, one whole ray per call (kernel variants 0 and 1)
 template <bool COUNT, bool SPH, bool COMPACT>
 __device__ __forceinline__ Hit trace8(const RenderParams &P, uint32_t *__restrict__ stack, rt_v3 o, rt_v3 d, Tally &tl) {
@@ -371,9 +385,9 @@ __device__ __forceinline__ Hit trace8(const RenderParams &P, uint32_t *__restric
     constexpr bool compact = COMPACT;
     const uint32_t stride = compact ? (uint32_t)RT_NODE8C_CHUNKS : P.wide_stride;
     const float ix = stuffed_inverse(d.x), iy = stuffed_inverse(d.y), iz = stuffed_inverse(d.z);
-    const float eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(o.x * ix)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(o.y * iy))),
-                                             fmaf(P.scene_abs[2], fabsf(iz), fabsf(o.z * iz)));
-    const float ox = wide_origin(compact, P.grid_lo[0], o.x, ix), oy = wide_origin(compact, P.grid_lo[1], o.y, iy), oz = wide_origin(compact, P.grid_lo[2], o.z, iz);
+    const float pad = slab_pad(P, o), pad2 = pad + pad;
+    const float ox = fmaf(-pad, fabsf(ix), wide_origin(compact, P.grid_lo[0], o.x, ix)), oy = fmaf(-pad, fabsf(iy), wide_origin(compact, P.grid_lo[1], o.y, iy)),
+                oz = fmaf(-pad, fabsf(iz), wide_origin(compact, P.grid_lo[2], o.z, iz));
     const uint32_t flip256 = ((__float_as_uint(ix) >> 31) | ((__float_as_uint(iy) >> 31) << 1) | ((__float_as_uint(iz) >> 31) << 2)) << 8;
     const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(P.nodes);
     uint32_t ng_base = 0, ng_mask = 0x0101u, tg_base = 0, tg_mask = 0;   // the root: the only child of a virtual group
@@ -406,7 +420,7 @@ __device__ __forceinline__ Hit trace8(const RenderParams &P, uint32_t *__restric
         if (kGuard && node + stride > P.n_node_chunks) { tl.guard++; return best; }
         if (COUNT) { tl.nodes++; if (first_active_lane()) tl.w_nodes++; }
         uint32_t imask, lmask;
-        const uint32_t h = test_node8<COMPACT>(P, nodes + node, ix, iy, iz, ox, oy, oz, eps, best.t, ng_base, tg_base, imask, lmask);
+        const uint32_t h = test_node8<COMPACT>(P, nodes + node, ix, iy, iz, ox, oy, oz, pad2, best.t, ng_base, tg_base, imask, lmask);
         ng_mask = (h & imask) | (imask << 8);
         tg_mask = (h & lmask) | (lmask << 8);
     }
@@ -817,7 +831,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
     Hit best;
     // slab constants of the current ray (see make_slab): kept as scalars, not
     // pairs, so the loop carries them in place
-    float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0, eps = 0;
+    float ix = 0, iy = 0, iz = 0, ox = 0, oy = 0, oz = 0, eps = 0;     // ox.. = -o * inv lowered by the axis' pad, eps = twice the pad per unit of |inv| (slab_pad)
     int phase = PH_FETCH;
     bool have_pixel = false;  // FETCH: a finished pixel-frame waits to be written out
     int32_t cur = 0;          // NODE: inner node reference (float4 index); LEAF: leaf reference (< 0)
@@ -843,9 +857,12 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
         auto stuff = [](float inv) { const uint32_t u = __float_as_uint(inv); return __uint_as_float((u & 0xFFFFFFE0u) | ((u >> 27) & 16u)); };
         ix = stuff(__builtin_amdgcn_rcpf(nz(S.dir.x))); iy = stuff(__builtin_amdgcn_rcpf(nz(S.dir.y))); iz = stuff(__builtin_amdgcn_rcpf(nz(S.dir.z)));
         ox = -(S.pos.x * ix); oy = -(S.pos.y * iy); oz = -(S.pos.z * iz);
-        eps = 4.76837158e-7f * fmaxf(fmaxf(fmaf(P.scene_abs[0], fabsf(ix), fabsf(ox)), fmaf(P.scene_abs[1], fabsf(iy), fabsf(oy))),
-                                     fmaf(P.scene_abs[2], fabsf(iz), fabsf(oz)));   // see make_slab
+        // per-axis pads: the entry planes' origin term lowered by pad * |inv| here, the exit planes' base raised by eps * |inv| = twice that
+        // in the node step, see slab_pad
+        const float pad = slab_pad(P, S.pos);
         if (COMPACT) { ox = fmaf(P.grid_lo[0], ix, ox); oy = fmaf(P.grid_lo[1], iy, oy); oz = fmaf(P.grid_lo[2], iz, oz); }   // into the corner grid's space
+        ox = fmaf(-pad, fabsf(ix), ox); oy = fmaf(-pad, fabsf(iy), oy); oz = fmaf(-pad, fabsf(iz), oz);
+        eps = pad + pad;
         best.t = kTMax; best.u = 0.0f; best.v = 0.0f; best.slot = kNoHit; best.gid = kNoHit; best.front = true;
         cur = 0; sptr = stack;
         if (WIDE) {
@@ -967,14 +984,15 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                         const float scale = __uint_as_float((e5 + (127u - RT_Q8_EXP_BIAS)) << 23);
                         refs = make_int2(__float_as_int(a.w), (int32_t)b.w);
                         const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
+                        const float cx = fmaf(eps, fabsf(ix), bx), cy = fmaf(eps, fabsf(iy), by), cz = fmaf(eps, fabsf(iz), bz);   // exit planes' base
                         const float sx = scale * ix, sy = scale * iy, sz = scale * iz;
                         const uint32_t px = __builtin_amdgcn_alignbit(b.x, b.x, rx), py = __builtin_amdgcn_alignbit(b.y, b.y, ry),
                                        pz = __builtin_amdgcn_alignbit(b.z, b.z, rz);
                         auto ub = [](uint32_t v, int k) { return (float)((v >> (8 * k)) & 255u); };
                         n0 = fmaxf(fmaxf(fmaf(ub(px, 0), sx, bx), fmaf(ub(py, 0), sy, by)), fmaxf(fmaf(ub(pz, 0), sz, bz), kTMin));
                         n1 = fmaxf(fmaxf(fmaf(ub(px, 1), sx, bx), fmaf(ub(py, 1), sy, by)), fmaxf(fmaf(ub(pz, 1), sz, bz), kTMin));
-                        f0 = fminf(fminf(fmaf(ub(px, 2), sx, bx), fmaf(ub(py, 2), sy, by)), fminf(fmaf(ub(pz, 2), sz, bz), best.t));
-                        f1 = fminf(fminf(fmaf(ub(px, 3), sx, bx), fmaf(ub(py, 3), sy, by)), fminf(fmaf(ub(pz, 3), sz, bz), best.t));
+                        f0 = fminf(fminf(fmaf(ub(px, 2), sx, cx), fmaf(ub(py, 2), sy, cy)), fminf(fmaf(ub(pz, 2), sz, cz), best.t));
+                        f1 = fminf(fminf(fmaf(ub(px, 3), sx, cx), fmaf(ub(py, 3), sy, cy)), fminf(fmaf(ub(pz, 3), sz, cz), best.t));
                     } else {
                         // 48-byte node: three loads; rotating each (hi << 16 | lo) f16 offset pair by 0 or 16 bits makes the
                         // low half the plane the ray ENTERS through, no min/max needed
@@ -982,17 +1000,18 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                         const uint4 b = ld4u(n + 1), c = ld4u(n + 2);
                         refs = make_int2(__float_as_int(a.w), (int32_t)b.w);
                         const float bx = fmaf(a.x, ix, ox), by = fmaf(a.y, iy, oy), bz = fmaf(a.z, iz, oz);
+                        const float cx = fmaf(eps, fabsf(ix), bx), cy = fmaf(eps, fabsf(iy), by), cz = fmaf(eps, fabsf(iz), bz);   // exit planes' base
                         const uint32_t p0x = __builtin_amdgcn_alignbit(b.x, b.x, rx), p0y = __builtin_amdgcn_alignbit(b.y, b.y, ry),
                                        p0z = __builtin_amdgcn_alignbit(b.z, b.z, rz);
                         const uint32_t p1x = __builtin_amdgcn_alignbit(c.x, c.x, rx), p1y = __builtin_amdgcn_alignbit(c.y, c.y, ry),
                                        p1z = __builtin_amdgcn_alignbit(c.z, c.z, rz);
                         n0 = fmaxf(fmaxf(fmaf(lo16(p0x), ix, bx), fmaf(lo16(p0y), iy, by)), fmaxf(fmaf(lo16(p0z), iz, bz), kTMin));
-                        f0 = fminf(fminf(fmaf(hi16(p0x), ix, bx), fmaf(hi16(p0y), iy, by)), fminf(fmaf(hi16(p0z), iz, bz), best.t));
+                        f0 = fminf(fminf(fmaf(hi16(p0x), ix, cx), fmaf(hi16(p0y), iy, cy)), fminf(fmaf(hi16(p0z), iz, cz), best.t));
                         n1 = fmaxf(fmaxf(fmaf(lo16(p1x), ix, bx), fmaf(lo16(p1y), iy, by)), fmaxf(fmaf(lo16(p1z), iz, bz), kTMin));
-                        f1 = fminf(fminf(fmaf(hi16(p1x), ix, bx), fmaf(hi16(p1y), iy, by)), fminf(fmaf(hi16(p1z), iz, bz), best.t));
+                        f1 = fminf(fminf(fmaf(hi16(p1x), ix, cx), fmaf(hi16(p1y), iy, cy)), fminf(fmaf(hi16(p1z), iz, cz), best.t));
                     }
-                    const bool h0 = n0 <= fmaf(f0, kFarSlack, eps);
-                    const bool h1 = n1 <= fmaf(f1, kFarSlack, eps);
+                    const bool h0 = n0 <= f0 * kFarSlack;
+                    const bool h1 = n1 <= f1 * kFarSlack;
                     // next reference: the nearer hit child; the other one (if hit) is pushed
                     const bool take1 = h1 && (!h0 || n1 < n0);
                     int32_t nxt = take1 ? refs.y : refs.x;

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(kBlock) void exp_trace_plain(const RenderParams P, 
         const float4 ro = rays[2u * (size_t)r], rd = rays[2u * (size_t)r + 1u];
         const Hit h = trace8<COUNT, SPH, true>(P, stack, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), tl);
         tl.rays++;
-        hits[r] = make_uint2(__float_as_uint(h.t), h.slot);
+        // counting launches return the ray's own work instead of its hit: (node visits, primitive tests)
+        hits[r] = COUNT ? make_uint2(tl.nodes, tl.tris) : make_uint2(__float_as_uint(h.t), h.slot);
     }
     if (COUNT) flush_tally<COUNT>(P, tl);       // (without counting: no atomics at all — 127 k waves adding to one address serialise)
 }

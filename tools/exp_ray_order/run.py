@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--size", default=None, help="WxH instead of the config's")
     ap.add_argument("--pmc", action="store_true")
+    ap.add_argument("--per-ray", action="store_true", help="only: the distribution of node visits per ray of the generation")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
@@ -101,6 +102,23 @@ def main():
     print(f"[exp] dumped generation (sample {args.sample}, bounce {args.bounce}) of {args.frames} frames at {W}x{H}: {n} rays of {slots} slots "
           f"in {time.time() - t0:.1f} s", flush=True)
     rt._check(L.rt_exp_set_rays(ctx.handle, rays.ctypes.data, n))
+    nonfinite = ~np.isfinite(rays[:, [0, 1, 2, 4, 5, 6]]).all(axis=1)
+    print(f"[exp] rays with a non-finite origin or direction component: {int(nonfinite.sum())}", flush=True)
+    if args.per_ray:
+        # how long is the longest ray?  (a launch of one generation is as long as its slowest ray: a dependent chain of node visits)
+        work = np.zeros((n, 2), np.uint32)
+        ms1 = np.zeros(1, np.float32)
+        rt._check(L.rt_exp_trace(ctx.handle, u.ctypes.data, None, 0, 1, 1, ms1.ctypes.data, work.ctypes.data, None))
+        v = work[:, 0].astype(np.int64)
+        qs = [50, 90, 99, 99.9, 99.99, 99.999, 100]
+        print("[exp] node visits per ray: mean %.1f; " % v.mean() + ", ".join(f"p{q}: {int(np.percentile(v, q))}" for q in qs), flush=True)
+        top = np.argsort(v)[-8:][::-1]
+        for i in top:
+            print(f"[exp]   ray {i}: {v[i]} node visits, {work[i, 1]} primitive tests, origin {rays[i, 0:3]}, direction {rays[i, 4:7]}, non-finite {bool(nonfinite[i])}", flush=True)
+        print(f"[exp] visits of the non-finite rays: {v[nonfinite][:16]}", flush=True)
+        print(f"[exp] rays above 1000 visits: {int((v > 1000).sum())}, above 10000: {int((v > 10000).sum())}; share of all visits in rays above 1000: {v[v > 1000].sum() / v.sum():.4f}", flush=True)
+        ctx.close()
+        return
 
     o, d = rays[:, 0:3], rays[:, 4:7]
     lo, hi = o.min(axis=0), o.max(axis=0)
