@@ -256,8 +256,8 @@ def report(args, cfg, rt, ctx, world, dt, rays, kernel_ms, launches, stats, cus,
                                                    "above 1 means the records are cache-resident and these bytes never reach HBM"}}
         # The on-chip ceilings (profiles/onchip.json, reduced from the PMC passes of the same command by tools/pmc_summary.py), each in
         # its counter's own unit against a peak calibrated with known instruction / lane-load counts (profiles/r3_calibration.txt):
-        #   L1 path:  CUs x clock x 1.48 TCP_TOTAL_CACHE_ACCESSES per clock per CU / the kernel's accesses per ray
-        #   VALU:     SIMDs x clock x 0.391 SQ_INSTS_VALU per clock per SIMD (fastest instruction class; FMA 0.310) / the kernel's wave instructions per ray
+        #   L1 path:  CUs x clock x 1.50 TCP_TOTAL_CACHE_ACCESSES per nominal clock per CU / the kernel's accesses per ray
+        #   VALU:     SIMDs x clock x 0.392 SQ_INSTS_VALU per nominal clock per SIMD (fastest instruction class; FMA 0.320) / the kernel's wave instructions per ray
         opath = os.path.join(ROOT, "profiles", "onchip.json")
         if os.path.exists(opath):
             oc = json.load(open(opath)).get(args.config)
@@ -266,19 +266,19 @@ def report(args, cfg, rt, ctx, world, dt, rays, kernel_ms, launches, stats, cus,
                 achieved_mrays = rays / launches / world / (kernel_ms * 1e-3) / 1e6
                 l1_peak = oc["l1_tag_lookups_per_clk_per_cu_peak"]
                 l1 = l1_peak * cus * clock_hz / oc["l1_tag_lookups_per_ray"] / 1e6
-                valu_peak, fma_peak = oc.get("valu_insts_per_simd_clk_peak", 0.391), oc.get("valu_insts_per_simd_clk_fma_peak", 0.310)
+                valu_peak, fma_peak = oc.get("valu_insts_per_simd_clk_peak", 0.392), oc.get("valu_insts_per_simd_clk_fma_peak", 0.320)
                 valu = valu_peak * cus * 4 * clock_hz / oc["valu_wave_insts_per_ray"] / 1e6
                 out["roofline"]["onchip"] = {
                     "bound": "l1_tag_lookups", "ceiling_mrays": l1, "achieved_mrays": achieved_mrays, "frac": achieved_mrays / l1,
                     "l1_tag_lookups_per_ray": oc["l1_tag_lookups_per_ray"], "l1_tag_lookups_per_clk_per_cu_peak": l1_peak,
-                    "valu": {"ceiling_mrays": valu, "frac": achieved_mrays / valu, "frac_of_fma_peak": achieved_mrays / (valu * fma_peak / valu_peak),
+                    "valu": {"ceiling_mrays": valu, "frac": achieved_mrays / valu, "rate_vs_all_fma_stream": achieved_mrays / (valu * fma_peak / valu_peak),
                              "wave_insts_per_ray": oc["valu_wave_insts_per_ray"], "insts_per_simd_clk_peak": valu_peak, "insts_per_simd_clk_fma_peak": fma_peak,
                              "insts_per_simd_clk_in_profile": oc.get("measured_valu_insts_per_simd_clk"), "lane_utilization": oc.get("valu_lane_utilization")},
                     "cus": cus, "clock_hz": clock_hz, "profile": oc.get("profile"), "kernel_source_sha256_of_profile": oc.get("kernel_source_sha256"),
                     "git_head_at_reduction": oc.get("git_head_at_reduction"), "stale": stale,
-                    "note": "ceilings = units x clock x calibrated peak rate of the counter (profiles/r3_calibration.txt: 1.48 TCP_TOTAL_CACHE_ACCESSES per clock per CU for "
-                            "divergent 16-byte lane-loads that hit L1; 0.391 SQ_INSTS_VALU per clock per SIMD for the fastest VALU class, 0.310 for v_fma_f32) / the kernel's own "
-                            "count per ray (profiles/onchip.json).  stale = the profile was taken with other device sources than this run's"}
+                    "note": "ceilings = units x nominal clock x calibrated peak rate of the counter (profiles/r3_calibration.txt: 1.50 TCP_TOTAL_CACHE_ACCESSES per clock per CU for "
+                            "divergent 16-byte lane-loads that hit L1; 0.392 SQ_INSTS_VALU per clock per SIMD for the fastest VALU class, 0.320 for v_fma_f32; all per NOMINAL clock, "
+                            "i.e. per unit of time) / the kernel's own count per ray (profiles/onchip.json).  stale = the profile was taken with other device sources than this run's"}
     return out
 
 

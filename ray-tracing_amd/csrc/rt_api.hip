@@ -963,11 +963,13 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
             ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm, ctx->node_wide ? (ctx->node_compact ? 3 : 2) : (ctx->node_q8 ? 1 : 0));
             ctx->persistent_sel = sel;
             // Resident workgroups per CU.  More waves hide more latency only while their rays' working set stays in the caches and the
-            // TLB; measured (8-ary nodes, ms per step at 3 / 4 / 5 workgroups): C4, 2 GB of records: 126 / 109 / 102; C5q, 10 GB:
-            // 64.7 / 58.5 / 63.8; C5, 39 GB: 509 / 574 / 698.  Hence by size, unless knob 103 says otherwise.
+            // TLB; measured (64-byte 8-ary nodes, ms per step in 4-step launches at 3 / 4 / 5 / 6 workgroups): C4, 2 GB of records:
+            // - / 92.4 / 83.1 / 78.4; C5q, 9.4 GB: 47.3 / 40.0 / 38.3 / 41.6; C5, 38 GB: 401 / 354 / 437 / -.  Hence by size, unless knob 103
+            // says otherwise.  (Round 2 measured this with the slice rays of slab_pad's comment still in every launch's tail and chose
+            // 4 and 3; each step down then hid part of that tail.)
             const uint64_t record_bytes = ctx->node_bytes + ctx->n_tris * (sizeof(DevTri) + sizeof(DevShade));
             int per_cu = ctx->tune[3];
-            if (per_cu <= 0) per_cu = record_bytes > (20ull << 30) ? 3 : (record_bytes > (4ull << 30) ? 4 : 0);
+            if (per_cu <= 0) per_cu = record_bytes > (20ull << 30) ? 4 : (record_bytes > (4ull << 30) ? 5 : 0);
             if (per_cu > 0 && ctx->cu_count > 0 && ctx->persistent_blocks > per_cu * ctx->cu_count)
                 ctx->persistent_blocks = per_cu * ctx->cu_count;
         }

@@ -6,9 +6,14 @@ import collections, csv, glob, hashlib, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # Calibrated peaks (profiles/r3_calibration.txt, tools/microbench/calibrate.hip: independent instruction streams, 6 waves per SIMD;
 # fully divergent 16-byte lane-loads that hit L1), in the counters' OWN units:
-VALU_PEAK_INSTS_PER_SIMD_CLK = 0.391     # SQ_INSTS_VALU per clock per SIMD of the fastest class (v_add_u32: 2.56 clocks); v_fma_f32 0.310, v_fma_mix / v_max3 / v_alignbit / v_mul_lo 0.22, v_rcp / v_sqrt 0.122
-VALU_FMA_INSTS_PER_SIMD_CLK = 0.310
-L1_PEAK_ACCESSES_PER_CU_CLK = 1.48       # TCP_TOTAL_CACHE_ACCESSES_sum per clock per CU (one per divergent lane-load, one per QUAD of lanes sharing a line)
+# All three are RATES PER NOMINAL CLOCK (hipDeviceAttributeClockRate, 2.4 GHz), i.e. per unit of TIME: the microbenchmark divides its
+# known counts by its own un-profiled HIP-event time, and so does this reducer with the kernel's (trace-pass time).  GRBM_GUI_ACTIVE / 8
+# is NOT used as the clock: under the VALU streams it reads 0.76 of the nominal clock (the part runs them at about 1.83 GHz), under the
+# gather kernels 1.00 — a fraction formed with it would compare rates at different clocks.
+NOMINAL_CLOCK_HZ = 2.4e9
+VALU_PEAK_INSTS_PER_SIMD_CLK = 0.392     # SQ_INSTS_VALU per nominal clock per SIMD of the fastest class (v_add_u32, v_mul_f32: 2.55 clocks); v_fma_f32 0.320, v_fma_mix / v_max3 / v_alignbit / v_cvt_f32_ubyte / v_min 0.23-0.24, v_mul_lo_u32 0.22, v_rcp / v_sqrt 0.122
+VALU_FMA_INSTS_PER_SIMD_CLK = 0.320
+L1_PEAK_ACCESSES_PER_CU_CLK = 1.50       # TCP_TOTAL_CACHE_ACCESSES_sum per nominal clock per CU (0.982 per divergent 16-byte lane-load x 1.502 lane-loads; one access per QUAD of lanes that shares a line)
 
 
 def source_stamp():
@@ -37,22 +42,25 @@ stats = glob.glob(os.path.join(src, 'trace/*/*kernel_stats.csv'))[0]
 kern = [r for r in csv.DictReader(open(stats)) if 'rt_render' in r['Name']][0]
 avg_ms = float(kern['AverageNs']) / 1e6
 d = {"kernel": kern['Name'], "calls": int(kern['Calls']), "avg_ms": avg_ms, "pmc_mean_per_launch": vals}
-cyc = vals.get('GRBM_GUI_ACTIVE', 0) / 8
-if cyc:
+gui = vals.get('GRBM_GUI_ACTIVE', 0) / 8
+cyc = avg_ms * 1e-3 * NOMINAL_CLOCK_HZ            # nominal clocks of one launch (time base of the calibrated peaks)
+if gui:
     d["derived"] = {
-        "shader_clock_GHz": cyc / (avg_ms * 1e-3) / 1e9,
+        "grbm_gui_active_clock_GHz": gui / (avg_ms * 1e-3) / 1e9,
+        "rate_time_base": "counter / (kernel time from the trace pass x 2.4 GHz nominal)",
         # VALU issue rate: wave64 VALU instructions per clock per SIMD (SQ_INSTS_VALU counts exactly one per wave-instruction:
         # profiles/r3_calibration.txt), against the CALIBRATED peaks of independent instruction streams at 6 waves per SIMD.
-        # No clamp: the fraction of the fastest class's peak cannot exceed 1; the fraction of the FMA peak can (a stream of
-        # two-operand integer adds issues faster than FMAs) and says how close the kernel's mix is to an all-FMA stream.
+        # No clamp: the fraction of the fastest class's peak cannot exceed 1.  valu_rate_vs_all_fma_stream is a RATIO of two rates, not a
+        # utilisation: the kernel's issue rate over that of a stream of nothing but v_fma_f32 (0.320), which a mix holding two-operand
+        # adds / multiplies (0.392) can exceed.
         # (Rounds 1 and 2 divided by a nominal 0.25 — a dependent-chain figure — and got 1.14 / 1.21.)
         "valu_insts_per_simd_clk": vals['SQ_INSTS_VALU'] / 1024 / cyc,
         "valu_frac_of_peak": vals['SQ_INSTS_VALU'] / 1024 / cyc / VALU_PEAK_INSTS_PER_SIMD_CLK,
-        "valu_frac_of_fma_peak": vals['SQ_INSTS_VALU'] / 1024 / cyc / VALU_FMA_INSTS_PER_SIMD_CLK,
+        "valu_rate_vs_all_fma_stream": vals['SQ_INSTS_VALU'] / 1024 / cyc / VALU_FMA_INSTS_PER_SIMD_CLK,
         # SQ_ACTIVE_INST_VALU counts 1 per 4-clock instruction and 2 per 8-clock one (v_rcp, v_sqrt, ...): the share of 8-clock instructions
         "valu_8clk_inst_fraction": vals['SQ_ACTIVE_INST_VALU'] / vals['SQ_INSTS_VALU'] - 1.0,
         "valu_lane_utilization": vals['SQ_THREAD_CYCLES_VALU'] / (vals['SQ_ACTIVE_INST_VALU'] * 64),
-        "waves_per_simd": vals['SQ_WAVE_CYCLES'] * 4 / 1024 / cyc,
+        "waves_per_simd": vals['SQ_WAVE_CYCLES'] * 4 / 1024 / gui,
         "l2_hit_rate": vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']),
         # MI355X_MICROARCH.md §HBM: FETCH_SIZE (KiB) reads exactly half of a wide streaming read on gfx950 -> x2;
         # WRITE_SIZE (KiB) is exact.  Scattered 16-B loads are uncalibrated: both figures are given.
@@ -70,7 +78,7 @@ try:
             rays = b["config"]["rays"]
 except OSError:
     pass
-if rays and cyc:
+if rays and gui:
     d["per_ray"] = {"rays_per_launch": rays,
                     "valu_wave_insts_per_ray": vals['SQ_INSTS_VALU'] / rays,
                     "valu_lane_insts_per_ray": vals['SQ_THREAD_CYCLES_VALU'] / 4 / rays if 'SQ_THREAD_CYCLES_VALU' in vals else None,
@@ -109,8 +117,8 @@ if out and len(sys.argv) > 3:
                           "measured_valu_insts_per_simd_clk": d["derived"]["valu_insts_per_simd_clk"],
                           "method": "rocprofv3 --pmc SQ_INSTS_VALU / TCP_TOTAL_CACHE_ACCESSES_sum per launch divided by the launch's exact device-side ray count; "
                                     "peaks in the counters' own units from profiles/r3_calibration.txt (tools/microbench/calibrate.hip under the same --pmc passes): "
-                                    "1.48 TCP_TOTAL_CACHE_ACCESSES per clock per CU (fully divergent 16-byte lane-loads, L1 hits), "
-                                    "0.391 / 0.310 SQ_INSTS_VALU per clock per SIMD (independent v_add_u32 / v_fma_f32 streams, 6 waves per SIMD)",
+                                    "1.50 TCP_TOTAL_CACHE_ACCESSES per nominal clock per CU (fully divergent 16-byte lane-loads, L1 hits), "
+                                    "0.392 / 0.320 SQ_INSTS_VALU per nominal clock per SIMD (independent v_add_u32 / v_fma_f32 streams, 6 waves per SIMD)",
                           "profile": out, **source_stamp()}
         json.dump(o, open(op, "w"), indent=1)
 if out:
