@@ -165,7 +165,11 @@ __device__ __forceinline__ void intersect_leaf(const DevTri *__restrict__ tris, 
 // far bound factor of the box test: covers the relative error of t (rcp 2^-23, the phased kernel's stuffed
 // inverse 2^-18, two roundings 2^-23) on both sides of the comparison
 constexpr float kFarSlack = 1.000012f;
+constexpr float kFarSlackStrict = 1.00001216f;   // the next f32 above kFarSlack: tn <= tf * kFarSlack implies tn < tf * kFarSlackStrict (tf > 0; tf <= 0 is a miss either way)
 typedef _Float16 rt_h2 __attribute__((ext_vector_type(2)));
+// min(a, b) as the bare instruction: fminf() canonicalises an operand the compiler cannot prove quiet (the committed hit's distance:
+// one v_max_f32 x, x per node step, a slow-class instruction); neither operand is ever a signalling NaN here
+__device__ __forceinline__ float min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float lo16(uint32_t w) { return (float)__builtin_bit_cast(rt_h2, w).x; }
 __device__ __forceinline__ float hi16(uint32_t w) { return (float)__builtin_bit_cast(rt_h2, w).y; }
 __device__ __forceinline__ uint4 ld4u(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
@@ -355,8 +359,7 @@ __device__ __forceinline__ uint32_t test_node8(const RenderParams &P, const floa
     const uint32_t rx = __float_as_uint(ix), ry = __float_as_uint(iy), rz = __float_as_uint(iz);
     const uint32_t QX[4] = {qx.x, qx.y, qx.z, qx.w}, QY[4] = {qy.x, qy.y, qy.z, qy.w}, QZ[4] = {qz.x, qz.y, qz.z, qz.w};
     uint32_t h = 0;
-    // children 7 .. 0, so that the mask can be built by shifting each hit in from below: h = 2 h + hit is ONE v_addc
-    // (carry-in = the compare's result) instead of a select and an or
+    // children 7 .. 0, so that the mask can be built by shifting each hit in from below
 #pragma unroll
     for (int p = 3; p >= 0; p--) {
         // [c(2p).lo, c(2p+1).lo, c(2p).hi, c(2p+1).hi] rotated by 0 or 16 bits: bytes 0, 1 = the planes the ray ENTERS through
@@ -365,9 +368,12 @@ __device__ __forceinline__ uint32_t test_node8(const RenderParams &P, const floa
 #pragma unroll
         for (int j = 1; j >= 0; j--) {
             const float tn = fmaxf(fmaxf(fmaf(ubyte_f(px, j), sx, bx), fmaf(ubyte_f(py, j), sy, by)), fmaxf(fmaf(ubyte_f(pz, j), sz, bz), kTMin));
-            const float tf = fminf(fminf(fmaf(ubyte_f(px, 2 + j), sx, cx), fmaf(ubyte_f(py, 2 + j), sy, cy)), fminf(fmaf(ubyte_f(pz, 2 + j), sz, cz), tbest));
-            const float lim = tf * kFarSlack;
-            asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(tn), "v"(lim) : "vcc");
+            const float tf = fminf(fminf(fmaf(ubyte_f(px, 2 + j), sx, cx), fmaf(ubyte_f(py, 2 + j), sy, cy)), min_raw(fmaf(ubyte_f(pz, 2 + j), sz, cz), tbest));
+            // hit <=> tn < tf * slack <=> the sign of tn - tf * slack (one FMA: its sign is that of the exact difference); the mask takes the
+            // sign bit in from below with ONE v_alignbit: h = h << 1 | sign.  (v_mul + v_cmp + v_addc before: 11.2 clocks of a SIMD per child
+            // against 7.5 by the rates of tools/microbench/calibrate.hip; strict '<' against a slack one ulp wider than kFarSlack loses nothing.)
+            const float x = fmaf(tf, -kFarSlackStrict, tn);
+            h = __builtin_amdgcn_alignbit(h, __float_as_uint(x), 31);
         }
     }
     return h & (imask | lmask);
@@ -870,7 +876,11 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
             flip256 = ((__float_as_uint(ix) >> 31) | ((__float_as_uint(iy) >> 31) << 1) | ((__float_as_uint(iz) >> 31) << 2)) << 8;
         }
         guard_steps = 0;
-        phase = PH_NODE;
+        // A ray with a NaN component hits nothing under the contract (every comparison of every primitive test fails; the oracle's
+        // brute force agrees) but v_max3 / v_min3 drop NaN operands, so the box test would let it into EVERY node: it goes straight
+        // to SHADE as a miss.  (A zero vertex normal is enough to make one: tangent_space() normalises a zero cross product.)
+        const bool nan_ray = __builtin_isunordered(S.dir.x, S.dir.y) | __builtin_isunordered(S.dir.z, S.pos.x) | __builtin_isunordered(S.pos.y, S.pos.z);
+        phase = nan_ray ? PH_SHADE : PH_NODE;
     };
     // 8-ary nodes: what a lane does next once its current step is done — primitives of the node just visited first, then
     // its inner children, then the youngest group on the stack; nothing left = the trace is finished
@@ -991,8 +1001,8 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                         auto ub = [](uint32_t v, int k) { return (float)((v >> (8 * k)) & 255u); };
                         n0 = fmaxf(fmaxf(fmaf(ub(px, 0), sx, bx), fmaf(ub(py, 0), sy, by)), fmaxf(fmaf(ub(pz, 0), sz, bz), kTMin));
                         n1 = fmaxf(fmaxf(fmaf(ub(px, 1), sx, bx), fmaf(ub(py, 1), sy, by)), fmaxf(fmaf(ub(pz, 1), sz, bz), kTMin));
-                        f0 = fminf(fminf(fmaf(ub(px, 2), sx, cx), fmaf(ub(py, 2), sy, cy)), fminf(fmaf(ub(pz, 2), sz, cz), best.t));
-                        f1 = fminf(fminf(fmaf(ub(px, 3), sx, cx), fmaf(ub(py, 3), sy, cy)), fminf(fmaf(ub(pz, 3), sz, cz), best.t));
+                        f0 = fminf(fminf(fmaf(ub(px, 2), sx, cx), fmaf(ub(py, 2), sy, cy)), min_raw(fmaf(ub(pz, 2), sz, cz), best.t));
+                        f1 = fminf(fminf(fmaf(ub(px, 3), sx, cx), fmaf(ub(py, 3), sy, cy)), min_raw(fmaf(ub(pz, 3), sz, cz), best.t));
                     } else {
                         // 48-byte node: three loads; rotating each (hi << 16 | lo) f16 offset pair by 0 or 16 bits makes the
                         // low half the plane the ray ENTERS through, no min/max needed
@@ -1006,9 +1016,9 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                         const uint32_t p1x = __builtin_amdgcn_alignbit(c.x, c.x, rx), p1y = __builtin_amdgcn_alignbit(c.y, c.y, ry),
                                        p1z = __builtin_amdgcn_alignbit(c.z, c.z, rz);
                         n0 = fmaxf(fmaxf(fmaf(lo16(p0x), ix, bx), fmaf(lo16(p0y), iy, by)), fmaxf(fmaf(lo16(p0z), iz, bz), kTMin));
-                        f0 = fminf(fminf(fmaf(hi16(p0x), ix, cx), fmaf(hi16(p0y), iy, cy)), fminf(fmaf(hi16(p0z), iz, cz), best.t));
+                        f0 = fminf(fminf(fmaf(hi16(p0x), ix, cx), fmaf(hi16(p0y), iy, cy)), min_raw(fmaf(hi16(p0z), iz, cz), best.t));
                         n1 = fmaxf(fmaxf(fmaf(lo16(p1x), ix, bx), fmaf(lo16(p1y), iy, by)), fmaxf(fmaf(lo16(p1z), iz, bz), kTMin));
-                        f1 = fminf(fminf(fmaf(hi16(p1x), ix, cx), fmaf(hi16(p1y), iy, cy)), fminf(fmaf(hi16(p1z), iz, cz), best.t));
+                        f1 = fminf(fminf(fmaf(hi16(p1x), ix, cx), fmaf(hi16(p1y), iy, cy)), min_raw(fmaf(hi16(p1z), iz, cz), best.t));
                     }
                     const bool h0 = n0 <= f0 * kFarSlack;
                     const bool h1 = n1 <= f1 * kFarSlack;

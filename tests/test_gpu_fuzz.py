@@ -159,3 +159,75 @@ def test_corrupted_scene_arrays_are_refused_and_leave_the_context_usable(rt, obj
                 ctx.spheres_upload(S)
                 assert render(ctx) == want, f"case {case}"
         assert refused == 60
+
+
+def _soup(obj_loader, n, seed, normal=(0.0, 1.0, 0.0), extent=8.0, size=0.25):
+    rng = np.random.default_rng(seed)
+    c = (rng.random((n, 1, 3)) - 0.5) * extent
+    p = (c + (rng.random((n, 3, 3)) - 0.5) * size).astype(np.float32)
+    V = np.zeros(3 * n, obj_loader.VERTEX_DTYPE)
+    V["position"] = p.reshape(-1, 3)
+    V["normal"] = normal
+    I = np.arange(3 * n, dtype=np.uint32)
+    P = np.zeros(1, obj_loader.PRIMITIVE_DTYPE)
+    P[0] = (0, 3 * n, 0, 3 * n, 0)
+    M = np.zeros(1, obj_loader.MODEL_DTYPE)
+    M["diffuse_color"] = (0.8, 0.6, 0.4)
+    return V, I, P, M
+
+
+@pytest.mark.parametrize("node_format", [1, 2, 3, 4])
+def test_axis_parallel_rays_do_not_visit_a_slice_of_the_tree(rt, oracle_mod, obj_loader, node_format):
+    """Rays that run nearly parallel to an axis (|d.x|, |d.y| ~ 1e-7: a camera with a field of view of a microradian) must cost what
+    other rays cost.  The box test's absolute error grows with 1 / |d_k|; as ONE pad shared by the three axes it switched the other two
+    slabs off, and such a ray visited every node whose x range held its origin (C4: 10,798 visits against a mean of 27, 25 ms at the end
+    of every launch).  The pads are per axis now (csrc/rt_kernels.hip slab_pad); the image is the brute-force oracle's either way."""
+    V, I, P, M = _soup(obj_loader, 200000, 3)
+    w, h = 32, 32
+    kw = dict(max_bounces=0, samples=4)
+    cam = ((0.013, 0.021, -9.0), np.pi / 2, 0.0)
+    scene = obj_loader.Scene(V, I, P, M)
+    ou = oracle_mod.make_uniform(w, h, *cam, fov=2e-6, **kw)
+    want, want_hits, cnt = oracle_mod.OracleScene(scene, build_bvh=False).render(ou, mode=0, want_hits=True)
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.RT_OPT_NODE_FORMAT, node_format)
+        ctx.set_option(rt.RT_OPT_AOV, 1)
+        ctx.set_option(rt.RT_OPT_COUNT_TRAVERSAL, 1)
+        ctx.scene_upload(V, I, P, M)
+        ctx.accum_resize(w, h)
+        ctx.dispatch(rt.make_uniform(w, h, *cam, fov=2e-6, **kw))
+        got, hits, st = ctx.accum_download(), ctx.aov_download(), ctx.stats()
+    assert st.rays == cnt.rays == w * h * 4
+    assert np.array_equal(hits, want_hits)
+    assert_images_identical(got, want, f"axis-parallel rays, format {node_format}")
+    # measured, node visits per ray through these 200,000 triangles: binary nodes 126 / 149 (48- / 32-byte records; 513 / 520 with the shared
+    # pad), 8-ary nodes 51 (180); a ray of an ordinary camera 49 and 21
+    bound = 250 if node_format in (1, 2) else 90
+    assert st.node_visits / st.rays < bound, (st.node_visits / st.rays, st.triangle_tests / st.rays)
+
+
+@pytest.mark.parametrize("node_format", [1, 4])
+def test_nan_rays_skip_the_tree(rt, oracle_mod, obj_loader, node_format):
+    """Zero vertex normals make NaN scatter directions (tangent_space() normalises a zero cross product).  Such a ray hits nothing under
+    the contract, the oracle's brute force agrees, and the kernel must not walk the tree for it: v_max3 / v_min3 drop NaN operands, so
+    its box test would pass everywhere."""
+    V, I, P, M = _soup(obj_loader, 6000, 5, normal=(0.0, 0.0, 0.0), extent=4.0, size=0.6)
+    w, h = 48, 32
+    kw = dict(max_bounces=3, samples=2)
+    cam = ((0.0, 0.0, -6.0), np.pi / 2, 0.0)
+    scene = obj_loader.Scene(V, I, P, M)
+    want, want_hits, cnt = oracle_mod.OracleScene(scene, build_bvh=False).render(oracle_mod.make_uniform(w, h, *cam, **kw), mode=0, want_hits=True)
+    assert cnt.hits > 500
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.RT_OPT_NODE_FORMAT, node_format)
+        ctx.set_option(rt.RT_OPT_AOV, 1)
+        ctx.set_option(rt.RT_OPT_COUNT_TRAVERSAL, 1)
+        ctx.scene_upload(V, I, P, M)
+        ctx.accum_resize(w, h)
+        ctx.dispatch(rt.make_uniform(w, h, *cam, **kw))
+        got, hits, st = ctx.accum_download(), ctx.aov_download(), ctx.stats()
+    assert st.rays == cnt.rays
+    assert np.array_equal(hits, want_hits)
+    assert_images_identical(got, want, f"NaN rays, format {node_format}")
+    assert np.isnan(want[..., :3]).any() or (want[..., :3] == 0).any()      # the NaN paths end as NaN -> 0 in tone_map
+    assert st.node_visits / st.rays < 100, st.node_visits / st.rays

@@ -16,8 +16,10 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Kind { FMA, FMA_MIX, MAX3, CVT_UBYTE, ALIGNBIT, CNDMASK, MUL_LO_U32, RCP, SQRT, ADD_U32, CNDMASK_S, MUL_F32, MIN_F32 };
-static const char *kind_name[] = {"v_fma_f32", "v_fma_mix_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_alignbit_b32", "v_cndmask_b32", "v_mul_lo_u32", "v_rcp_f32", "v_sqrt_f32", "v_add_u32", "v_cndmask_b32 (sgpr mask)", "v_mul_f32", "v_min_f32"};
+enum Kind { FMA, FMA_MIX, MAX3, CVT_UBYTE, ALIGNBIT, CNDMASK, MUL_LO_U32, RCP, SQRT, ADD_U32, CNDMASK_S, MUL_F32, MIN_F32,
+            PERM, AND_B32, AND_OR, LSHL_OR, LSHLREV, BFE, BFI, CVT_F32_U32, CMP_ADDC, ADD_F32, FMAC, PK_FMA, PK_MUL, MED3, MAX_F32, BCNT, XOR, MAD_U24, CVT_PK_FP8, SUB_F32, LSHL_ADD, ADD3, KINDS };
+static const char *kind_name[] = {"v_fma_f32", "v_fma_mix_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_alignbit_b32", "v_cndmask_b32", "v_mul_lo_u32", "v_rcp_f32", "v_sqrt_f32", "v_add_u32", "v_cndmask_b32 (sgpr mask)", "v_mul_f32", "v_min_f32",
+    "v_perm_b32", "v_and_b32", "v_and_or_b32", "v_lshl_or_b32", "v_lshlrev_b32", "v_bfe_u32", "v_bfi_b32", "v_cvt_f32_u32", "v_cmp_le_f32 + v_addc_co_u32 (2 insts)", "v_add_f32", "v_fmac_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_med3_f32", "v_max_f32", "v_bcnt_u32_b32", "v_xor_b32", "v_mad_u32_u24", "v_cvt_pk_f32_fp8", "v_sub_f32", "v_lshl_add_u32", "v_add3_u32"};
 
 template <int K>
 __device__ __forceinline__ void op(float &a, float b, float c) {
@@ -34,6 +36,49 @@ __device__ __forceinline__ void op(float &a, float b, float c) {
     if (K == CNDMASK_S) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(0x5555555555555555ull));
     if (K == MUL_F32) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b));
     if (K == MIN_F32) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(0x07020c0cu));
+    if (K == AND_B32) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == AND_OR) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a) : "v"(b));
+    if (K == LSHLREV) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a));
+    if (K == BFE) asm volatile("v_bfe_u32 %0, %0, 1, 30" : "+v"(a));
+    if (K == BFI) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == CVT_F32_U32) asm volatile("v_cvt_f32_u32 %0, %1" : "+v"(a) : "v"(b));
+    if (K == CMP_ADDC) asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(a) : "v"(b), "v"(c) : "vcc");
+    if (K == ADD_F32) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == MED3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == MAX_F32) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == BCNT) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == MAD_U24) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == CVT_PK_FP8) { float2 t2; asm volatile("v_cvt_pk_f32_fp8 %0, %1" : "=v"(t2) : "v"(a)); a = t2.x; }
+    if (K == SUB_F32) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+    if (K == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a) : "v"(b));
+    if (K == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+}
+// packed f32: two accumulators per instruction (64-bit register pairs)
+template <int K>
+__device__ __forceinline__ void op2(float2 &a, float2 b, float2 c) {
+    if (K == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+}
+template <int K>
+__global__ __launch_bounds__(256) void valu_stream2(int iters, float *out) {
+    float2 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[k] = make_float2((float)(threadIdx.x + k), 1.0f);
+    const float2 b = make_float2(1.0001f, 0.9999f), c = make_float2(0.5f, 0.25f);
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) op2<K>(acc[k], b, c);
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += acc[k].x + acc[k].y;
+    if (s == 123.456f) out[0] = s;
 }
 
 // 16 independent accumulators x 4 rounds = 64 VALU instructions per loop iteration, nothing else vector in the loop
@@ -110,6 +155,17 @@ int main() {
     time_valu(CNDMASK_S, valu_stream<CNDMASK_S>);
     time_valu(MUL_F32, valu_stream<MUL_F32>);
     time_valu(MIN_F32, valu_stream<MIN_F32>);
+    if (getenv("CALIBRATE_MORE")) {       // instruction classes beyond the ones the roofline uses (developer; not part of the --pmc join)
+        time_valu(PERM, valu_stream<PERM>); time_valu(AND_B32, valu_stream<AND_B32>); time_valu(AND_OR, valu_stream<AND_OR>);
+        time_valu(LSHL_OR, valu_stream<LSHL_OR>); time_valu(LSHLREV, valu_stream<LSHLREV>); time_valu(BFE, valu_stream<BFE>);
+        time_valu(BFI, valu_stream<BFI>); time_valu(CVT_F32_U32, valu_stream<CVT_F32_U32>); time_valu(CMP_ADDC, valu_stream<CMP_ADDC>);
+        time_valu(ADD_F32, valu_stream<ADD_F32>); time_valu(FMAC, valu_stream<FMAC>);
+        time_valu(PK_FMA, valu_stream2<PK_FMA>); time_valu(PK_MUL, valu_stream2<PK_MUL>);
+        time_valu(MED3, valu_stream<MED3>); time_valu(MAX_F32, valu_stream<MAX_F32>); time_valu(BCNT, valu_stream<BCNT>);
+        time_valu(XOR, valu_stream<XOR>); time_valu(MAD_U24, valu_stream<MAD_U24>); time_valu(CVT_PK_FP8, valu_stream<CVT_PK_FP8>);
+        time_valu(SUB_F32, valu_stream<SUB_F32>); time_valu(LSHL_ADD, valu_stream<LSHL_ADD>); time_valu(ADD3, valu_stream<ADD3>);
+        return 0;
+    }
 
     const int gblocks = cus * 8, giters = 2000;
     for (uint32_t lines : {128u, 32768u}) {               // 8 KB (L1-resident) and 2 MB (L2-resident)
