@@ -38,7 +38,10 @@ for f in sorted(glob.glob(os.path.join(src, 'pmc_*/*/*counter_collection.csv')))
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
         vals[k] = sum(v) / len(v); n[k] = len(v)
-stats = glob.glob(os.path.join(src, 'trace/*/*kernel_stats.csv'))[0]
+stats = glob.glob(os.path.join(src, 'trace/*/*kernel_stats.csv'))
+if len(stats) != 1:      # gpurun merges every call's files into gpurun_out/: two runs under one tag would be averaged together
+    sys.exit(f"{src}: {len(stats)} trace passes found, expected 1 (delete gpurun_out/prof_<tag> before profiling under the same tag again)")
+stats = stats[0]
 kern = [r for r in csv.DictReader(open(stats)) if 'rt_render' in r['Name']][0]
 avg_ms = float(kern['AverageNs']) / 1e6
 d = {"kernel": kern['Name'], "calls": int(kern['Calls']), "avg_ms": avg_ms, "pmc_mean_per_launch": vals}
