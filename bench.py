@@ -114,13 +114,26 @@ def cpu_baseline_and_byte_model(cfg, sample_w, sample_h, timed_w, timed_h, audit
 
 
 def cpu_model():
+    """Model name plus what identifies the part when the name is generic (a VM shows "AMD EPYC"): family / model / stepping, cache, CPUs
+    this process may use."""
+    info = {}
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+            if ":" in line:
+                k, v = (x.strip() for x in line.split(":", 1))
+                if k in ("model name", "cpu family", "model", "stepping", "cache size") and k not in info:
+                    info[k] = v
+            elif info:
+                break
     except OSError:
         pass
-    return "unknown"
+    name = info.get("model name", "unknown")
+    ident = ", ".join(f"{k} {info[k]}" for k in ("cpu family", "model", "stepping", "cache size") if k in info)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 0
+    return f"{name} ({ident}; {usable} CPUs usable by this process)" if ident else name
 
 
 def self_launch(n):
