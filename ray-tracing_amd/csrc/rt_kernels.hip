@@ -159,7 +159,7 @@ __device__ __forceinline__ void intersect_leaf(const DevTri *__restrict__ tris, 
 // inv comes from v_rcp_f32 (1 ulp); a zero direction component is nudged to 1e-30
 // so no inf/NaN appears.  Error of t: relative 2^-22 |t| from inv and the last
 // rounding (covered by the kFarSlack factor), absolute <= 2^-24 (2|o| + |lo|) |inv|
-// from o*inv and base, covered PER AXIS by pad * |inv_k|, pad = 2^-21 max_k (|o_k| + R_k),
+// from o*inv and base, covered PER AXIS by pad * |inv_k|, pad = 2^-20 max_k (|o_k| + R_k),
 // R_k = max |coordinate| of the root box (RenderParams::scene_abs): entry distances are
 // lowered by it (folded into the origin term), exit distances raised (slab_pad).
 // far bound factor of the box test: covers the relative error of t (rcp 2^-23, the phased kernel's stuffed
@@ -174,14 +174,18 @@ __device__ __forceinline__ float lo16(uint32_t w) { return (float)__builtin_bit_
 __device__ __forceinline__ float hi16(uint32_t w) { return (float)__builtin_bit_cast(rt_h2, w).y; }
 __device__ __forceinline__ uint4 ld4u(const void *p) { return *reinterpret_cast<const uint4 *>(p); }
 
-// The absolute error of one axis' slab distances, 2^-21 (|o| + R) |inv| (see above), as a pad of THAT axis alone: the box
-// tests lower the entry planes' base by pad * |inv| and raises the exit planes' by the same, pad = 2^-21 max_k (|o_k| + R_k) (one
-// number per ray: what differs between the axes is |inv|), instead of adding the largest of the three products to the far bound.  A shared pad is harmless until a ray runs nearly parallel to an axis: |d.x| = 5.6e-9 makes the x
-// pad 1,500 scene units, and as a shared pad that switched the y and z slabs off — such a ray visited every node whose x range
-// holds its origin (C4: 10,798 node visits + 26,414 primitive tests against a mean of 27 + 4.8; 19 rays of 8.1 M above 1,000
-// visits), a dependent chain of 25 ms at the end of a launch whose other 8 M rays took 3 ms (tools/exp_ray_order/run.py --per-ray).
+// The absolute error of one axis' slab distances as a pad of THAT axis alone.  Worst case over the roundings of the longest chain
+// (64-byte 8-ary record: o * inv, grid_lo * inv - that, the pad's own subtraction, cell * inv times the corner index, the base,
+// step * inv times the plane byte; grid span <= 3 R): 2^-24 (4 |o| + 9 R) |inv|, R = max |coordinate| of the root box; binary nodes
+// 2^-24 (3 |o| + R) |inv|.  pad = 2^-20 max_k (|o_k| + R_k) covers it 1.8 times over.  The box tests lower the entry planes' base by
+// pad * |inv_k| and raise the exit planes' by the same (one number per ray: what differs between the axes is |inv|) instead of adding
+// the largest of the three products to the far bound.  A shared pad is harmless until a ray runs nearly parallel to an axis:
+// |d.x| = 5.6e-9 makes the x pad 1,500 scene units, and as a shared pad that switched the y and z slabs off — such a ray visited
+// every node whose x range holds its origin (C4: 10,798 node visits + 26,414 primitive tests against a mean of 27 + 4.8; 19 rays of
+// 8.1 M above 1,000 visits), a dependent chain of 25 ms at the end of a launch whose other 8 M rays took 3 ms
+// (tools/exp_ray_order/run.py --per-ray).  The relative error of t (the stuffed inverse's 2^-18, roundings) is kFarSlack's part.
 __device__ __forceinline__ float slab_pad(const RenderParams &P, rt_v3 o) {
-    return 4.76837158e-7f * fmaxf(fmaxf(P.scene_abs[0] + fabsf(o.x), P.scene_abs[1] + fabsf(o.y)), P.scene_abs[2] + fabsf(o.z));
+    return 9.5367431640625e-7f * fmaxf(fmaxf(P.scene_abs[0] + fabsf(o.x), P.scene_abs[1] + fabsf(o.y)), P.scene_abs[2] + fabsf(o.z));
 }
 
 struct Slab {

@@ -117,6 +117,13 @@ for it in range(args.iters):
     d = d / max(np.linalg.norm(d), 1e-20)
     yaw = float(np.arctan2(d[2], d[0]) + rng.uniform(-0.3, 0.3))
     pitch = float(np.clip(np.arcsin(d[1]) + rng.uniform(-0.3, 0.3), -1.5, 1.5))
+    if rng.random() < 0.12:                              # a camera ALONG an axis with a narrow field of view: rays (nearly) parallel to one or two axes —
+        yaw = float(int(rng.integers(0, 4)) * np.pi / 2)  # the case in which the box test's per-axis pads matter (slab_pad), and at pitch +-pi/2 a degenerate camera basis
+        pitch = 0.0 if rng.random() < 0.7 else float(rng.choice([-1.0, 1.0]) * np.pi / 2)
+        kw["fov"] = float(10.0 ** rng.uniform(-7, -0.5))
+        fwd = np.array([np.cos(yaw) * np.cos(pitch), np.sin(pitch), np.sin(yaw) * np.cos(pitch)])
+        cam = centre - fwd * spread * rng.uniform(1.5, 4.0) + (rng.random(3) - 0.5) * spread * 0.5
+        notes.add('axis camera')
     textures = []
     if rng.random() < 0.25:                              # textures: index 0 = none, k = texture k - 1, beyond = black
         textures = [rng.integers(0, 256, (int(rng.integers(1, 10)), int(rng.integers(1, 10)), 4), dtype=np.uint8) for _ in range(int(rng.integers(1, 4)))]
