@@ -161,6 +161,9 @@ def test_corrupted_scene_arrays_are_refused_and_leave_the_context_usable(rt, obj
         assert refused == 60
 
 
+_ORACLE_CACHE = {}
+
+
 def _soup(obj_loader, n, seed, normal=(0.0, 1.0, 0.0), extent=8.0, size=0.25):
     rng = np.random.default_rng(seed)
     c = (rng.random((n, 1, 3)) - 0.5) * extent
@@ -186,9 +189,10 @@ def test_axis_parallel_rays_do_not_visit_a_slice_of_the_tree(rt, oracle_mod, obj
     w, h = 32, 32
     kw = dict(max_bounces=0, samples=4)
     cam = ((0.013, 0.021, -9.0), np.pi / 2, 0.0)
-    scene = obj_loader.Scene(V, I, P, M)
-    ou = oracle_mod.make_uniform(w, h, *cam, fov=2e-6, **kw)
-    want, want_hits, cnt = oracle_mod.OracleScene(scene, build_bvh=False).render(ou, mode=0, want_hits=True)
+    if "axis" not in _ORACLE_CACHE:           # brute force over 200,000 triangles: once for the four formats
+        ou = oracle_mod.make_uniform(w, h, *cam, fov=2e-6, **kw)
+        _ORACLE_CACHE["axis"] = oracle_mod.OracleScene(obj_loader.Scene(V, I, P, M), build_bvh=False).render(ou, mode=0, want_hits=True)
+    want, want_hits, cnt = _ORACLE_CACHE["axis"]
     with rt.Context(0) as ctx:
         ctx.set_option(rt.RT_OPT_NODE_FORMAT, node_format)
         ctx.set_option(rt.RT_OPT_AOV, 1)

@@ -17,9 +17,10 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 enum Kind { FMA, FMA_MIX, MAX3, CVT_UBYTE, ALIGNBIT, CNDMASK, MUL_LO_U32, RCP, SQRT, ADD_U32, CNDMASK_S, MUL_F32, MIN_F32,
-            PERM, AND_B32, AND_OR, LSHL_OR, LSHLREV, BFE, BFI, CVT_F32_U32, CMP_ADDC, ADD_F32, FMAC, PK_FMA, PK_MUL, MED3, MAX_F32, BCNT, XOR, MAD_U24, CVT_PK_FP8, SUB_F32, LSHL_ADD, ADD3, KINDS };
+            PERM, AND_B32, AND_OR, LSHL_OR, LSHLREV, BFE, BFI, CVT_F32_U32, CMP_ADDC, ADD_F32, FMAC, PK_FMA, PK_MUL, MED3, MAX_F32, BCNT, XOR, MAD_U24, CVT_PK_FP8, SUB_F32, LSHL_ADD, ADD3, MOV_SDWA_B2, OR_SDWA, MOV_B32, ADD_F32_SDWA, MUL_F32_SDWA, KINDS };
 static const char *kind_name[] = {"v_fma_f32", "v_fma_mix_f32", "v_max3_f32", "v_cvt_f32_ubyte1", "v_alignbit_b32", "v_cndmask_b32", "v_mul_lo_u32", "v_rcp_f32", "v_sqrt_f32", "v_add_u32", "v_cndmask_b32 (sgpr mask)", "v_mul_f32", "v_min_f32",
-    "v_perm_b32", "v_and_b32", "v_and_or_b32", "v_lshl_or_b32", "v_lshlrev_b32", "v_bfe_u32", "v_bfi_b32", "v_cvt_f32_u32", "v_cmp_le_f32 + v_addc_co_u32 (2 insts)", "v_add_f32", "v_fmac_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_med3_f32", "v_max_f32", "v_bcnt_u32_b32", "v_xor_b32", "v_mad_u32_u24", "v_cvt_pk_f32_fp8", "v_sub_f32", "v_lshl_add_u32", "v_add3_u32"};
+    "v_perm_b32", "v_and_b32", "v_and_or_b32", "v_lshl_or_b32", "v_lshlrev_b32", "v_bfe_u32", "v_bfi_b32", "v_cvt_f32_u32", "v_cmp_le_f32 + v_addc_co_u32 (2 insts)", "v_add_f32", "v_fmac_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_med3_f32", "v_max_f32", "v_bcnt_u32_b32", "v_xor_b32", "v_mad_u32_u24", "v_cvt_pk_f32_fp8", "v_sub_f32", "v_lshl_add_u32", "v_add3_u32",
+    "v_mov_b32_sdwa dst_sel:BYTE_2 preserve src0_sel:BYTE_1", "v_or_b32_sdwa src0_sel:BYTE_1", "v_mov_b32", "v_add_f32_sdwa src0_sel:WORD_1", "v_mul_f32_sdwa src0_sel:BYTE_1"};
 
 template <int K>
 __device__ __forceinline__ void op(float &a, float b, float c) {
@@ -56,6 +57,11 @@ __device__ __forceinline__ void op(float &a, float b, float c) {
     if (K == SUB_F32) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a) : "v"(b));
     if (K == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(a) : "v"(b));
     if (K == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+    if (K == MOV_SDWA_B2) asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1" : "+v"(a) : "v"(b));
+    if (K == OR_SDWA) asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(b), "v"(c));
+    if (K == MOV_B32) asm volatile("v_mov_b32 %0, %1" : "=v"(a) : "v"(b));
+    if (K == ADD_F32_SDWA) asm volatile("v_add_f32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(a) : "v"(b));
+    if (K == MUL_F32_SDWA) asm volatile("v_mul_f32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(a) : "v"(b));
 }
 // packed f32: two accumulators per instruction (64-bit register pairs)
 template <int K>
@@ -164,6 +170,8 @@ int main() {
         time_valu(MED3, valu_stream<MED3>); time_valu(MAX_F32, valu_stream<MAX_F32>); time_valu(BCNT, valu_stream<BCNT>);
         time_valu(XOR, valu_stream<XOR>); time_valu(MAD_U24, valu_stream<MAD_U24>); time_valu(CVT_PK_FP8, valu_stream<CVT_PK_FP8>);
         time_valu(SUB_F32, valu_stream<SUB_F32>); time_valu(LSHL_ADD, valu_stream<LSHL_ADD>); time_valu(ADD3, valu_stream<ADD3>);
+        time_valu(MOV_SDWA_B2, valu_stream<MOV_SDWA_B2>); time_valu(OR_SDWA, valu_stream<OR_SDWA>); time_valu(MOV_B32, valu_stream<MOV_B32>);
+        time_valu(ADD_F32_SDWA, valu_stream<ADD_F32_SDWA>); time_valu(MUL_F32_SDWA, valu_stream<MUL_F32_SDWA>);
         return 0;
     }
 
