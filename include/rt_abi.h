@@ -199,6 +199,10 @@ typedef struct RtStats {
                                           four fetches and one 64-byte line per visit);
                                       0 (default) = by size: 48-byte binary nodes while the nodes stay in the caches, 64-byte 8-ary
                                           nodes once they would exceed ~12 MiB.  Formats 2-4 need a scene extent <= 2^18 (else 1 is used). */
+#define RT_OPT_SAMPLER         9   /* the texture sampler of shaders/misc.wgsl:6-8.  The reference creates it inside the un-vendored `compute` crate
+                                      (src/main.rs:43 `gpu.create_sampler()`), so its state is UNPINNED; the default 0 = wgpu's SamplerDescriptor
+                                      defaults.  bit 0: 1 = linear (bilinear, f32 weights, texel centres at +0.5) instead of nearest;
+                                      bit 1: 1 = repeat instead of clamp-to-edge.  Takes effect at the next dispatch. */
 
 typedef struct rt_context rt_context;
 

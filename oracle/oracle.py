@@ -52,6 +52,8 @@ def lib(alt: bool = False):
                                           C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_int]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_scene_set_front_face_cw.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_scene_set_sampler.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_sample_rgb.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
         L.oracle_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_scene_triangles.restype = C.c_uint64
         L.oracle_scene_triangles.argtypes = [C.c_void_p]
@@ -129,6 +131,15 @@ class OracleScene:
             self._tex_w = np.array([t.shape[1] for t in self._tex], np.uint32)
             self._tex_h = np.array([t.shape[0] for t in self._tex], np.uint32)
             L.oracle_scene_set_textures(self.handle, self._tex_ptrs, self._tex_w.ctypes.data, self._tex_h.ctypes.data, len(self._tex))
+
+    def sample_rgb(self, texture: int, u: float, v: float):
+        out = np.zeros(3, np.float32)
+        lib(self.alt).oracle_sample_rgb(self.handle, texture, C.c_float(u), C.c_float(v), out.ctypes.data)
+        return out
+
+    def set_sampler(self, sampler: int):
+        """RT_OPT_SAMPLER of the product: bit 0 linear filter, bit 1 repeat addressing (0 = nearest, clamp to edge)."""
+        lib(self.alt).oracle_scene_set_sampler(self.handle, int(sampler))
 
     def __del__(self):
         if getattr(self, "handle", None):

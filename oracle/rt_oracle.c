@@ -94,6 +94,7 @@ typedef struct {
     ONode *nodes;
     uint64_t n_nodes;
     int front_face_cw;
+    int sampler;                 /* RT_OPT_SAMPLER of the product: bit 0 linear, bit 1 repeat */
     /* textures[i]: RGBA8 rows as uploaded, i.e. ALREADY flipped vertically
      * (src/scene.rs:77); texture ids in materials are 1-based (src/scene.rs:170-174) */
     const uint8_t *const *textures;
@@ -247,15 +248,46 @@ typedef struct { v3 direction, color; } OScatter;
  * its filter/address modes are UNPINNED; the contract takes wgpu's SamplerDescriptor
  * defaults — nearest filtering, clamp-to-edge — on an Rgba8Unorm texture:
  * texel = clamp(floor(uv * size), 0, size-1), channel = byte / 255. */
+static int tex_index(float f) {            /* floor value -> int; NaN and anything below -2^30 -> -2^30, above 2^30 -> 2^30 */
+    f = (f > -1073741824.0f) ? f : -1073741824.0f;
+    f = (f < 1073741824.0f) ? f : 1073741824.0f;
+    return (int)f;
+}
+static uint32_t tex_address(int i, uint32_t n, int repeat) {
+    if (repeat) { int m = i % (int)n; return (uint32_t)(m < 0 ? m + (int)n : m); }
+    return (uint32_t)(i < 0 ? 0 : (i > (int)n - 1 ? (int)n - 1 : i));
+}
+static v3 texel_rgb(const OScene *sc, uint32_t texture, uint32_t x, uint32_t y) {
+    const uint8_t *px = sc->textures[texture] + 4 * ((size_t)y * sc->tex_w[texture] + x);
+    return V((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+/* sc->sampler (RT_OPT_SAMPLER of the product; the reference's own sampler state is unpinned): bit 0 linear — texel centres at +0.5,
+ * f32 weights, ((T00 (1-a) + T10 a) (1-b)) + ((T01 (1-a) + T11 a) b) — bit 1 repeat addressing; 0 = nearest, clamp to edge. */
 static v3 sample_rgb(const OScene *sc, uint32_t texture, const float *uv) {
     if (texture >= sc->n_textures) return V(0.0f, 0.0f, 0.0f);
     uint32_t w = sc->tex_w[texture], h = sc->tex_h[texture];
+    const int repeat = (sc->sampler & 2) != 0;
+    if (sc->sampler & 1) {
+        const float ux = uv[0] * (float)w - 0.5f, uy = uv[1] * (float)h - 0.5f;
+        const float x0f = floorf(ux), y0f = floorf(uy);
+        float a = ux - x0f, b = uy - y0f;
+        a = (a >= 0.0f) ? a : 0.0f; b = (b >= 0.0f) ? b : 0.0f;              /* NaN -> 0 */
+        const int x0 = tex_index(x0f), y0 = tex_index(y0f);
+        const uint32_t xa = tex_address(x0, w, repeat), xb = tex_address(x0 + 1, w, repeat);
+        const uint32_t ya = tex_address(y0, h, repeat), yb = tex_address(y0 + 1, h, repeat);
+        const v3 t00 = texel_rgb(sc, texture, xa, ya), t10 = texel_rgb(sc, texture, xb, ya), t01 = texel_rgb(sc, texture, xa, yb), t11 = texel_rgb(sc, texture, xb, yb);
+        const float ia = 1.0f - a, ib = 1.0f - b;
+        return add(scale(add(scale(t00, ia), scale(t10, a)), ib), scale(add(scale(t01, ia), scale(t11, a)), b));
+    }
+    if (repeat) {
+        const int x0 = tex_index(floorf(uv[0] * (float)w)), y0 = tex_index(floorf(uv[1] * (float)h));
+        return texel_rgb(sc, texture, tex_address(x0, w, 1), tex_address(y0, h, 1));
+    }
     float fx = floorf(uv[0] * (float)w), fy = floorf(uv[1] * (float)h);
     fx = (fx > 0.0f) ? fx : 0.0f; fy = (fy > 0.0f) ? fy : 0.0f;          /* NaN -> 0 */
     fx = (fx < (float)(w - 1)) ? fx : (float)(w - 1);
     fy = (fy < (float)(h - 1)) ? fy : (float)(h - 1);
-    const uint8_t *px = sc->textures[texture] + 4 * ((size_t)(uint32_t)fy * w + (uint32_t)fx);
-    return V((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    return texel_rgb(sc, texture, (uint32_t)fx, (uint32_t)fy);
 }
 
 /* shaders/ray.wgsl:12-32 */
@@ -827,6 +859,13 @@ OScene *oracle_scene_create(const OVertex *vertices, uint64_t n_vertices,
     return sc;
 }
 void oracle_scene_set_front_face_cw(OScene *sc, int cw) { sc->front_face_cw = cw; }
+void oracle_scene_set_sampler(OScene *sc, int sampler) { sc->sampler = sampler & 3; }
+/* the sampler alone (tests/test_textures.py checks it against a numpy restatement) */
+void oracle_sample_rgb(const OScene *sc, uint32_t texture, float u, float v, float *rgb) {
+    const float uv[2] = {u, v};
+    v3 c = sample_rgb(sc, texture, uv);
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
 void oracle_scene_set_textures(OScene *sc, const uint8_t *const *textures, const uint32_t *w, const uint32_t *h, uint32_t n) {
     sc->textures = textures; sc->tex_w = w; sc->tex_h = h; sc->n_textures = n;
 }

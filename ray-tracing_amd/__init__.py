@@ -60,6 +60,7 @@ RT_OPT_REFIT = 5
 RT_OPT_NODE_STRIDE = 6
 RT_OPT_FRAME_PIPELINE = 7
 RT_OPT_NODE_FORMAT = 8
+RT_OPT_SAMPLER = 9
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_option",

@@ -27,8 +27,8 @@
 #include "rt_math.h"
 #include "rt_pack.h"
 
-hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream);
-int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, int fmt);
+hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, int ext, int persistent_blocks, hipStream_t stream);
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, int ext, bool lds_materials, int fmt);
 hipError_t rt_launch_capture(const float *accum, uint8_t *rgb, size_t n_pixels, hipStream_t stream);
 hipError_t rt_launch_deinterleave(const float *gathered, float *image, const RtGatherLayout &L, hipStream_t stream);
 hipError_t rt_launch_refit(DevTri *tris, const DevShade *shade, const float *xform, RtRefitBox *tribox, uint64_t n_slots, float4 *chunks,
@@ -160,6 +160,7 @@ struct rt_context {
     uint64_t dispatches = 0, launches = 0;
 
     bool opt_count = false, opt_aov = false, opt_cw = false;
+    uint32_t opt_sampler = 0;        // RT_OPT_SAMPLER
     int opt_refit = 2;               // RT_OPT_REFIT: 0 rebuild, 1 host refit, 2 device refit
     int opt_node_stride = 0;
     int opt_node_format = 0;         // RT_OPT_NODE_FORMAT: 0 by size, 1 48-byte nodes, 2 32-byte q8 nodes
@@ -912,6 +913,7 @@ int make_params(rt_context *ctx, const RtUniform &u, uint32_t n_frames, unsigned
     P.max_bounces = u.max_bounces; P.samples = u.samples;
     P.stack_entries = ctx->stack_entries;
     P.front_face_cw = ctx->opt_cw ? 1u : 0u;
+    P.sampler = ctx->opt_sampler;
     P.exposure = u.exposure; P.environment = u.environment;
     memcpy(P.cam_pos, u.camera.position, 12);
     // camera basis: camera_direction() + ray_direction(), shaders/ray.wgsl:1-10,51-60.
@@ -951,14 +953,17 @@ int make_params(rt_context *ctx, const RtUniform &u, uint32_t n_frames, unsigned
     return RT_OK;
 }
 
+// which kernel instance a scene needs: 0 = triangles, untextured; 1 = + sphere records; 2 = + textures
+int kernel_ext(const rt_context *ctx) { return ctx->n_textures > 0 ? 2 : (ctx->hs->spheres.empty() ? 0 : 1); }
+
 int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned char *static_scratch = nullptr) {
     RenderParams P;
     { int r = make_params(ctx, u, n_frames, static_scratch, P); if (r) return r; }
     if (ctx->opt_kernel != 1) {
         RT_HIP(hipMemsetAsync(P.queue, 0, sizeof(DevQueue), ctx->stream));     // the head must start at zero, whatever the last call left
-        const bool ext = !ctx->hs->spheres.empty() || ctx->n_textures > 0;
+        const int ext = kernel_ext(ctx);
         const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
-        const int sel = (ctx->node_compact ? 64 : 0) | (ctx->node_wide ? 32 : 0) | (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext ? 1 : 0);
+        const int sel = (ctx->node_compact ? 64 : 0) | (ctx->node_wide ? 32 : 0) | (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext << 8);
         if (ctx->persistent_blocks == 0 || ctx->persistent_sel != sel) {
             ctx->persistent_blocks = rt_persistent_blocks(ctx->device, ctx->stack_entries, ctx->opt_count, ctx->opt_aov, ext, ldsm, ctx->node_wide ? (ctx->node_compact ? 3 : 2) : (ctx->node_q8 ? 1 : 0));
             ctx->persistent_sel = sel;
@@ -981,7 +986,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
         RT_HIP(hipMemsetAsync(P.probe, 0, probe_waves * 24, ctx->stream));
     }
 #endif
-    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, !ctx->hs->spheres.empty() || ctx->n_textures > 0, ctx->persistent_blocks, ctx->stream));
+    RT_HIP(rt_launch_render(P, ctx->opt_kernel, ctx->opt_count, ctx->opt_aov, kernel_ext(ctx), ctx->persistent_blocks, ctx->stream));
 #ifdef RT_TAIL_PROBE
     if (P.probe) {
         std::vector<unsigned long long> pr(3 * probe_waves), ends;
@@ -1151,6 +1156,9 @@ int rt_set_option(rt_context *ctx, int key, int64_t value) {
             ctx->opt_kernel = (int)value;
             return RT_OK;
         case RT_OPT_FRONT_FACE_CW: ctx->opt_cw = value != 0; return RT_OK;
+        case RT_OPT_SAMPLER:
+            if (value < 0 || value > 3) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_SAMPLER: 0..3 (bit 0 linear, bit 1 repeat)");
+            ctx->opt_sampler = (uint32_t)value; return RT_OK;
         case RT_OPT_REFIT:
             if (value < 0 || value > 2) return fail(RT_ERR_INVALID_ARGUMENT, "RT_OPT_REFIT: 0, 1 or 2");
             ctx->opt_refit = (int)value;

@@ -157,7 +157,8 @@ struct RenderParams {
                                          // node_wide = 1: 80-byte 8-ary nodes (DevNode8), 2: 64-byte ones (DevNode8c); `nodes` points at them
     float grid_lo[3];                    // DevNode8c: lower corner of the corner grid
     uint32_t grid_cell_bits[3];          // DevNode8c: bit pattern of (grid cell * 2^-8), a power of two, per axis
-    uint32_t pad_grid[2];
+    uint32_t sampler;                    // RT_OPT_SAMPLER: bit 0 linear filter, bit 1 repeat addressing (0 = nearest, clamp to edge)
+    uint32_t pad_grid;
     uint32_t n_textures, n_materials;   // n_materials: records behind `materials`
     float *accum;            // local rows x W x 4 f32
     uint32_t *aov;           // local rows x W x 2 u32, or null

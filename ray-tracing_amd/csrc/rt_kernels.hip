@@ -27,6 +27,8 @@
 // v_fma_mix_f32 and a widened far bound (see Slab / the node step below).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rt_device.h"
 #include "rt_math.h"
 #include "rt_pack.h"
@@ -457,17 +459,48 @@ __device__ __forceinline__ rt_v3 rand_cosine_hemisphere_vector(uint32_t &seed, r
     return tangent_space(normal, s);
 }
 
-// shaders/misc.wgsl:6-8 with a nearest / clamp-to-edge sampler on an Rgba8Unorm texture
-// (sampler unpinned, see rt_abi.h rt_textures_upload): texel = clamp(floor(uv*size), 0, size-1)
+// shaders/misc.wgsl:6-8 on an Rgba8Unorm texture.  The reference's sampler state is unpinned (rt_abi.h RT_OPT_SAMPLER); P.sampler:
+// 0 (default) nearest / clamp-to-edge: texel = clamp(floor(uv * size), 0, size - 1);
+// bit 0 linear: texel centres at +0.5, f32 weights, ((T00 (1-a) + T10 a) (1-b)) + ((T01 (1-a) + T11 a) b);
+// bit 1 repeat: texel index modulo the size.  Same arithmetic as oracle/rt_oracle.c sample_rgb().
+__device__ __forceinline__ int tex_index(float f) {           // floor value -> int; NaN and anything below -2^30 -> -2^30, above 2^30 -> 2^30
+    f = (f > -1073741824.0f) ? f : -1073741824.0f;
+    f = (f < 1073741824.0f) ? f : 1073741824.0f;
+    return (int)f;
+}
+__device__ __forceinline__ uint32_t tex_address(int i, uint32_t n, bool repeat) {
+    if (repeat) { int m = i % (int)n; return (uint32_t)(m < 0 ? m + (int)n : m); }
+    return (uint32_t)(i < 0 ? 0 : (i > (int)n - 1 ? (int)n - 1 : i));
+}
+__device__ __forceinline__ rt_v3 texel_rgb(const RenderParams &P, const DevTexture &t, uint32_t x, uint32_t y) {
+    const uint32_t px = P.texels[t.offset + y * t.width + x];
+    return v3((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);
+}
 __device__ __forceinline__ rt_v3 sample_rgb(const RenderParams &P, uint32_t texture, float u, float v) {
     if (texture >= P.n_textures) return v3(0.0f, 0.0f, 0.0f);
     const DevTexture t = P.textures[texture];
+    const bool repeat = (P.sampler & 2u) != 0u;
+    if (P.sampler & 1u) {
+        const float ux = u * (float)t.width - 0.5f, uy = v * (float)t.height - 0.5f;
+        const float x0f = floorf(ux), y0f = floorf(uy);
+        float a = ux - x0f, b = uy - y0f;
+        a = (a >= 0.0f) ? a : 0.0f; b = (b >= 0.0f) ? b : 0.0f;              // NaN (a non-finite uv) -> 0
+        const int x0 = tex_index(x0f), y0 = tex_index(y0f);
+        const uint32_t xa = tex_address(x0, t.width, repeat), xb = tex_address(x0 + 1, t.width, repeat);
+        const uint32_t ya = tex_address(y0, t.height, repeat), yb = tex_address(y0 + 1, t.height, repeat);
+        const rt_v3 t00 = texel_rgb(P, t, xa, ya), t10 = texel_rgb(P, t, xb, ya), t01 = texel_rgb(P, t, xa, yb), t11 = texel_rgb(P, t, xb, yb);
+        const float ia = 1.0f - a, ib = 1.0f - b;
+        return ((t00 * ia + t10 * a) * ib) + ((t01 * ia + t11 * a) * b);
+    }
+    if (repeat) {
+        const int x0 = tex_index(floorf(u * (float)t.width)), y0 = tex_index(floorf(v * (float)t.height));
+        return texel_rgb(P, t, tex_address(x0, t.width, true), tex_address(y0, t.height, true));
+    }
     float fx = floorf(u * (float)t.width), fy = floorf(v * (float)t.height);
     fx = (fx > 0.0f) ? fx : 0.0f; fy = (fy > 0.0f) ? fy : 0.0f;          // NaN -> 0
     fx = (fx < (float)(t.width - 1)) ? fx : (float)(t.width - 1);
     fy = (fy < (float)(t.height - 1)) ? fy : (float)(t.height - 1);
-    const uint32_t px = P.texels[t.offset + (uint32_t)fy * t.width + (uint32_t)fx];
-    return v3((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);
+    return texel_rgb(P, t, (uint32_t)fx, (uint32_t)fy);
 }
 
 // shaders/main.wgsl:104-108, pow(x, 5.0) as ((x*x)*(x*x))*x
@@ -563,7 +596,8 @@ __device__ __forceinline__ void finish_pixel(const RenderParams &P, const PixelS
 
 // Everything of sample()'s loop body after the trace (main.wgsl:46-69).
 // Returns true when the path ended (miss, or the bounce budget is spent).
-template <bool AOV, bool SPH, bool LDSM = false>
+// SPH: sphere records may be hit; TEX: materials may name textures (the phased kernel has an instance without that code: EXT below)
+template <bool AOV, bool SPH, bool LDSM = false, bool TEX = SPH>
 __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S, const Hit &h_in) {
     Hit h = h_in;
     if (AOV && S.first_ray) {
@@ -613,9 +647,9 @@ __device__ __forceinline__ bool shade_core(const RenderParams &P, PixelState &S,
             float smoothness = 1.0f - m2.x;
             rt_v3 scatter_normal = normal;
             rt_v3 diffuse_color = v3(m0.y, m0.z, m0.w);
-            const float4 m3 = SPH ? mat_chunk(3) : m0;               // texture ids: only instances with textures read them
+            const float4 m3 = TEX ? mat_chunk(3) : m0;               // texture ids: only instances with textures read them
             const uint32_t mat_diffuse_texture = __float_as_uint(m3.y), mat_normal_texture = __float_as_uint(m3.z);
-            if (SPH && (mat_normal_texture | mat_diffuse_texture) != 0u) {
+            if (TEX && (mat_normal_texture | mat_diffuse_texture) != 0u) {
                 // trace.uv, main.wgsl:96 (spheres: uv = 0)
                 float tu = 0.0f, tv = 0.0f;
                 if (!(__float_as_uint(s3.w) & 0x80000000u)) {
@@ -818,9 +852,10 @@ constexpr uint32_t kFreshPixel = 0xFFFFFFFFu;   // PixelState::bounce of a pixel
 // RAYLIST (developer instances, tools/exp_ray_order/): the same scheduler and traversal over a LIST of rays instead of pixels — FETCH
 // takes ray P.aov[q] (or q when P.aov is null) of the P.stage_stride rays in P.stage (origin, direction: two float4 each) and SHADE
 // only stores the committed hit (t bits, slot) to ((uint2 *)P.accum)[ray]: what a wavefront tracer's trace pass would run.
-template <bool COUNT, bool AOV, bool SPH, bool LDSM, int FMT, bool RAYLIST = false>
+// EXT: 0 = triangles, untextured; 1 = + sphere records; 2 = + textures (the sampler's code costs the sphere instance registers it has no use for)
+template <bool COUNT, bool AOV, int EXT, bool LDSM, int FMT, bool RAYLIST = false>
 __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED_WAVES) void rt_render_phased(const RenderParams P) {
-    constexpr bool Q8 = FMT == 1, WIDE = FMT >= 2, COMPACT = FMT == 3;
+    constexpr bool Q8 = FMT == 1, WIDE = FMT >= 2, COMPACT = FMT == 3, SPH = EXT >= 1, TEX = EXT >= 2;
     constexpr int kPrioNode = WIDE ? RT_PRIO_NODE_WIDE : RT_PRIO_NODE_BINARY, kPrioLeaf = WIDE ? RT_PRIO_LEAF_WIDE : RT_PRIO_LEAF_BINARY;
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
@@ -1113,7 +1148,7 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
 #endif
                 if (!fresh) {
                     tl.rays++;
-                    if (shade_core<AOV, SPH, LDSM>(P, S, best)) {
+                    if (shade_core<AOV, SPH, LDSM, TEX>(P, S, best)) {
                         S.total = S.total + S.light;                // main.wgsl:26
                         S.sample++;
                         more = S.sample < P.samples;
@@ -1270,50 +1305,30 @@ hipError_t launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, const Ren
 // Persistent grid size: the number of 256-thread workgroups of the given kernel
 // instance that are resident at once (register/LDS limited), so every wave
 // lives for the whole launch.
-template <bool LDSM, int FMT>
-static const void *phased_instance(int sel) {
-    switch (sel) {
-        case 0: return (const void *)rt_render_phased<false, false, false, LDSM, FMT>;
-        case 1: return (const void *)rt_render_phased<false, false, true, LDSM, FMT>;
-        case 2: return (const void *)rt_render_phased<false, true, false, LDSM, FMT>;
-        case 3: return (const void *)rt_render_phased<false, true, true, LDSM, FMT>;
-        case 4: return (const void *)rt_render_phased<true, false, false, LDSM, FMT>;
-        case 5: return (const void *)rt_render_phased<true, false, true, LDSM, FMT>;
-        case 6: return (const void *)rt_render_phased<true, true, false, LDSM, FMT>;
-        default: return (const void *)rt_render_phased<true, true, true, LDSM, FMT>;
-    }
+// One value of a run-time flag as a compile-time constant: f(std::integral_constant<...>)
+template <class F> static auto with_bool(bool b, F f) { return b ? f(std::true_type{}) : f(std::false_type{}); }
+template <class F> static auto with_int3(int v, F f) {          // 0..2
+    return v == 2 ? f(std::integral_constant<int, 2>{}) : (v == 1 ? f(std::integral_constant<int, 1>{}) : f(std::integral_constant<int, 0>{}));
+}
+template <class F> static auto with_int4(int v, F f) {          // 0..3
+    return v == 3 ? f(std::integral_constant<int, 3>{}) : (v == 2 ? f(std::integral_constant<int, 2>{}) : (v == 1 ? f(std::integral_constant<int, 1>{}) : f(std::integral_constant<int, 0>{})));
+}
+// the phased kernel's instance for (count, aov, ext, materials in LDS, node format) handed to f as a kernel pointer
+template <class F> static auto with_phased_instance(bool count, bool aov, int ext, bool ldsm, int fmt, F f) {
+    return with_bool(count, [&](auto C) { return with_bool(aov, [&](auto A) { return with_int3(ext, [&](auto E) { return with_bool(ldsm, [&](auto L) {
+        return with_int4(fmt, [&](auto M) { return f(rt_render_phased<decltype(C)::value, decltype(A)::value, decltype(E)::value, decltype(L)::value, decltype(M)::value>); }); }); }); }); });
 }
 
-// fmt: 0 = 48-byte binary nodes, 1 = 32-byte binary nodes, 2 = 80-byte 8-ary nodes, 3 = 64-byte 8-ary nodes
-int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, bool spheres, bool lds_materials, int fmt) {
+// ext: 0 = triangles, untextured; 1 = + spheres; 2 = + textures.  fmt: 0 = 48-byte binary nodes, 1 = 32-byte binary nodes, 2 = 80-byte 8-ary nodes, 3 = 64-byte 8-ary nodes
+int rt_persistent_blocks(int device, uint32_t stack_entries, bool count, bool aov, int ext, bool lds_materials, int fmt) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 256 * 4;
     int per_cu = 0;
     const size_t lds = fmt >= 2 ? (size_t)(stack_entries / 2u) * kBlock * 6u : (size_t)stack_entries * kBlock * sizeof(uint32_t);
     // the instances differ in register count (and static LDS), hence in how many workgroups fit
-    const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
-    const void *fn;
-    if (lds_materials) fn = fmt == 3 ? phased_instance<true, 3>(sel) : (fmt == 2 ? phased_instance<true, 2>(sel) : (fmt == 1 ? phased_instance<true, 1>(sel) : phased_instance<true, 0>(sel)));
-    else fn = fmt == 3 ? phased_instance<false, 3>(sel) : (fmt == 2 ? phased_instance<false, 2>(sel) : (fmt == 1 ? phased_instance<false, 1>(sel) : phased_instance<false, 0>(sel)));
+    const void *fn = with_phased_instance(count, aov, ext, lds_materials, fmt, [](auto kernel) { return (const void *)kernel; });
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlock, lds) != hipSuccess || per_cu < 1) per_cu = 4;
     return per_cu * prop.multiProcessorCount;
-}
-
-// LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS); FMT: the node format
-template <bool COUNT, bool AOV, bool SPH>
-static hipError_t launch_phased(const RenderParams &P, dim3 grid, size_t lds, hipStream_t stream) {
-    const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
-    const int fmt = P.node_wide ? (int)P.node_wide + 1 : (P.node_q8 ? 1 : 0);
-    if (ldsm) {
-        if (fmt == 3) return launch(rt_render_phased<COUNT, AOV, SPH, true, 3>, grid, lds, stream, P);
-        if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, true, 2>, grid, lds, stream, P);
-        if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, true, 1>, grid, lds, stream, P);
-        return launch(rt_render_phased<COUNT, AOV, SPH, true, 0>, grid, lds, stream, P);
-    }
-    if (fmt == 3) return launch(rt_render_phased<COUNT, AOV, SPH, false, 3>, grid, lds, stream, P);
-    if (fmt == 2) return launch(rt_render_phased<COUNT, AOV, SPH, false, 2>, grid, lds, stream, P);
-    if (fmt == 1) return launch(rt_render_phased<COUNT, AOV, SPH, false, 1>, grid, lds, stream, P);
-    return launch(rt_render_phased<COUNT, AOV, SPH, false, 0>, grid, lds, stream, P);
 }
 
 // variant 2 (and the blend of a multi-frame launch).  Lives in its own translation unit: see the Makefile on
@@ -1323,21 +1338,13 @@ static size_t phased_lds_bytes(uint32_t stack_entries, bool wide) {
     return wide ? (size_t)(stack_entries / 2u) * kBlock * 6u : (size_t)stack_entries * kBlock * sizeof(uint32_t);
 }
 
-hipError_t rt_launch_phased(const RenderParams &P, bool count, bool aov, bool spheres, unsigned blocks, size_t lds, hipStream_t stream) {
+hipError_t rt_launch_phased(const RenderParams &P, bool count, bool aov, int ext, unsigned blocks, size_t lds, hipStream_t stream) {
     const dim3 grid(blocks);
     lds = phased_lds_bytes(P.stack_entries, P.node_wide != 0u);
-    const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
-    hipError_t e = hipSuccess;
-    switch (sel) {
-        case 0: e = launch_phased<false, false, false>(P, grid, lds, stream); break;
-        case 1: e = launch_phased<false, false, true>(P, grid, lds, stream); break;
-        case 2: e = launch_phased<false, true, false>(P, grid, lds, stream); break;
-        case 3: e = launch_phased<false, true, true>(P, grid, lds, stream); break;
-        case 4: e = launch_phased<true, false, false>(P, grid, lds, stream); break;
-        case 5: e = launch_phased<true, false, true>(P, grid, lds, stream); break;
-        case 6: e = launch_phased<true, true, false>(P, grid, lds, stream); break;
-        default: e = launch_phased<true, true, true>(P, grid, lds, stream); break;
-    }
+    // LDSM: the workgroup keeps the scene's material records in LDS (rt_device.h RT_LDS_MATERIALS); FMT: the node format
+    const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
+    const int fmt = P.node_wide ? (int)P.node_wide + 1 : (P.node_q8 ? 1 : 0);
+    const hipError_t e = with_phased_instance(count, aov, ext, ldsm, fmt, [&](auto kernel) { return launch(kernel, grid, lds, stream, P); });
     if (e != hipSuccess || P.n_frames <= 1u) return e;
     const size_t n_pixels = (size_t)P.local_rows * P.width;
     if (n_pixels) rt_blend_frames<<<dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, stream>>>(P, n_pixels);
@@ -1346,7 +1353,7 @@ hipError_t rt_launch_phased(const RenderParams &P, bool count, bool aov, bool sp
 #endif  // RT_TU_PHASED
 
 #ifdef RT_TU_SIMPLE
-hipError_t rt_launch_phased(const RenderParams &P, bool count, bool aov, bool spheres, unsigned blocks, size_t lds, hipStream_t stream);
+hipError_t rt_launch_phased(const RenderParams &P, bool count, bool aov, int ext, unsigned blocks, size_t lds, hipStream_t stream);
 
 // variants 0 and 1 (the A/B baselines)
 template <bool COUNT, bool AOV, bool SPH>
@@ -1356,7 +1363,8 @@ static hipError_t launch_simple(const RenderParams &P, int variant, dim3 tile_gr
 }
 
 // Host-side launcher.  Dynamic LDS = stack_entries x 256 lanes x 4 B.
-hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, bool spheres, int persistent_blocks, hipStream_t stream) {
+hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool aov, int ext, int persistent_blocks, hipStream_t stream) {
+    const bool spheres = ext != 0;      // variants 0 / 1: one instance for spheres and textures
     const uint32_t tiles = P.tiles_x * P.local_bands;
     if (tiles == 0) return hipSuccess;
     const size_t lds = (size_t)P.stack_entries * kBlock * sizeof(uint32_t);
@@ -1366,7 +1374,7 @@ hipError_t rt_launch_render(const RenderParams &P, int variant, bool count, bool
     uint32_t blocks = (uint32_t)persistent_blocks;
     if ((uint64_t)blocks > (chunks + 3) / 4) blocks = (uint32_t)((chunks + 3) / 4);
     if (blocks == 0) blocks = 1;
-    if (variant == 2) return rt_launch_phased(P, count, aov, spheres, blocks, lds, stream);
+    if (variant == 2) return rt_launch_phased(P, count, aov, ext, blocks, lds, stream);
     dim3 pgrid(blocks);
     const int sel = (count ? 4 : 0) | (aov ? 2 : 0) | (spheres ? 1 : 0);
     switch (sel) {

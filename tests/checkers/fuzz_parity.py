@@ -150,6 +150,8 @@ for it in range(args.iters):
     osc = oracle.OracleScene(scene, transforms=T, spheres=S, build_bvh=args.big)
     omode = 1 if args.big else 0
     oracle.lib().oracle_scene_set_front_face_cw(osc.handle, int(cw))
+    sampler = int(rng.integers(0, 4)) if textures else 0      # RT_OPT_SAMPLER: nearest / linear x clamp / repeat
+    osc.set_sampler(sampler)
     if n_frames == 1:
         want, want_hits, cnt = osc.render(oracle.make_uniform(w, h, cam, yaw, pitch, **kw), mode=omode, want_hits=True)
     else:                                                # the cold-start frame sequence of src/app.rs:78-96
@@ -162,6 +164,7 @@ for it in range(args.iters):
         ctx.set_option(rt.RT_OPT_COUNT_TRAVERSAL, int(counting))
         ctx.set_option(rt.RT_OPT_REFIT, refit)
         ctx.set_option(rt.RT_OPT_FRONT_FACE_CW, int(cw))
+        ctx.set_option(rt.RT_OPT_SAMPLER, sampler)
         ctx.scene_upload(V, I, P, M)
         if S is not None:
             ctx.spheres_upload(S)

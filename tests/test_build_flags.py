@@ -58,7 +58,7 @@ def test_uniform_branch_flag_only_where_no_divergent_loop_exists(tmp_path):
     subprocess.run(BASE + flag + ["-DRT_TU_PHASED", src, "-o", phased], check=True, stderr=subprocess.DEVNULL)
     subprocess.run(BASE + ["-DRT_TU_SIMPLE", src, "-o", simple], check=True, stderr=subprocess.DEVNULL)
     p, s = divergent_loop_back_edges(phased), divergent_loop_back_edges(simple)
-    assert sum("rt_render_phased" in k for k in p) == 64 and not any("rt_render_persistent" in k or "rt_render_tiles" in k for k in p)
+    assert sum("rt_render_phased" in k for k in p) == 96 and not any("rt_render_persistent" in k or "rt_render_tiles" in k for k in p)
     assert {k: v for k, v in p.items() if v} == {}, "a divergent loop in the unit built with -structurizecfg-skip-uniform-regions"
     # the detector sees the per-lane traversal loops of variants 0 / 1
     assert all(v >= 1 for k, v in s.items() if "rt_render_persistent" in k or "rt_render_tiles" in k) and len(s) == 16

@@ -322,3 +322,136 @@ def test_png_decoder_random_files(rt, tmp_path):
         if ask_pil:                                      # (PIL keys sub-byte grey differently and reduces 16 bits by truncation)
             pil = np.array(Image.open(str(tmp_path / f"{name}.png")).convert("RGBA"), np.uint8)
             assert np.array_equal(got, pil), f"{name}: differs from PIL"
+
+
+# ---- RT_OPT_SAMPLER: the sampler state the reference leaves to the `compute` crate (src/main.rs:43), as an option on both sides ----
+
+def _np_sample(img, u, v, sampler):
+    """numpy restatement of sample_rgb() (oracle/rt_oracle.c, csrc/rt_kernels.hip) for one uv; img = [h, w, 4] uint8 as UPLOADED (flipped)."""
+    f32 = np.float32
+    h, w = img.shape[:2]
+    rgb = lambda x, y: img[y, x, :3].astype(f32) / f32(255.0)
+    repeat = bool(sampler & 2)
+    def addr(i, n, plus=0):          # floor value -> int saturated to +-2^30 (NaN -> -2^30), then the address mode
+        i = -(2 ** 30) if not (i > -(2.0 ** 30)) else (2 ** 30 if i > 2.0 ** 30 else int(i))
+        i += plus
+        return i % n if repeat else min(max(i, 0), n - 1)
+    if sampler & 1:
+        ux, uy = f32(u) * f32(w) - f32(0.5), f32(v) * f32(h) - f32(0.5)
+        x0, y0 = np.floor(ux), np.floor(uy)
+        with np.errstate(invalid="ignore"):
+            a, b = f32(ux - x0), f32(uy - y0)
+        a, b = (a if a >= 0 else f32(0.0)), (b if b >= 0 else f32(0.0))          # NaN -> 0
+        ia, ib = f32(1.0) - a, f32(1.0) - b
+        t00, t10 = rgb(addr(x0, w), addr(y0, h)), rgb(addr(x0, w, 1), addr(y0, h))
+        t01, t11 = rgb(addr(x0, w), addr(y0, h, 1)), rgb(addr(x0, w, 1), addr(y0, h, 1))
+        return ((t00 * ia + t10 * a) * ib) + ((t01 * ia + t11 * a) * b)
+    if not repeat:                   # the default path clamps in float (NaN -> 0)
+        fx, fy = np.floor(f32(u) * f32(w)), np.floor(f32(v) * f32(h))
+        fx, fy = (fx if fx > 0 else 0.0), (fy if fy > 0 else 0.0)
+        return rgb(int(min(fx, w - 1)), int(min(fy, h - 1)))
+    return rgb(addr(np.floor(f32(u) * f32(w)), w), addr(np.floor(f32(v) * f32(h)), h))
+
+
+def _emissive_textured_quad(obj_loader, rng, uv_lo, uv_hi):
+    """One quad facing the camera whose diffuse texture is seen through ONE bounce onto a white sky: colour = texel * sky."""
+    V = np.zeros(4, obj_loader.VERTEX_DTYPE)
+    V["position"] = [(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)]
+    V["normal"] = (0.0, 0.0, -1.0)
+    V["uv"] = [(uv_lo, uv_lo), (uv_hi, uv_lo), (uv_hi, uv_hi), (uv_lo, uv_hi)]
+    I = np.array([0, 2, 1, 0, 3, 2], np.uint32)
+    P = np.zeros(1, obj_loader.PRIMITIVE_DTYPE)
+    P[0] = (0, 4, 0, 6, 0)
+    M = np.zeros(1, obj_loader.MODEL_DTYPE)
+    M["diffuse_color"] = (1.0, 1.0, 1.0)
+    M["diffuse_texture"] = 1
+    tex = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+    return V, I, P, M, tex
+
+
+@pytest.mark.parametrize("sampler", [0, 1, 2, 3])
+def test_oracle_sampler_modes_match_numpy_restatement(oracle_mod, obj_loader, sampler):
+    """oracle_sample_rgb() against the numpy restatement, bit for bit, over a grid of uvs from -2.6 to 3.7 (clamp and repeat differ outside
+    [0, 1]) plus texel centres, texel edges and non-finite uvs."""
+    rng = np.random.default_rng(11)
+    V, I, P, M, tex = _emissive_textured_quad(obj_loader, rng, -0.6, 1.7)
+    osc = oracle_mod.OracleScene(obj_loader.Scene(V, I, P, M, textures=[tex]))
+    osc.set_sampler(sampler)
+    up = tex[::-1]                                           # as uploaded (src/scene.rs:77)
+    us = list(np.linspace(-2.6, 3.7, 41)) + [0.0, 1.0, 0.5 / 7, 1.5 / 7, 1.0 / 7, 6.5 / 7, -1.0 / 7, 1e9, -1e9]
+    vs = list(np.linspace(-2.6, 3.7, 37)) + [0.0, 1.0, 0.5 / 5, 1.0 / 5, 4.5 / 5, 3e9]
+    seen = set()
+    for v in vs:
+        for u in us:
+            got = osc.sample_rgb(0, u, v)
+            want = _np_sample(up, u, v, sampler).astype(np.float32)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (sampler, u, v, got, want)
+            seen.add(tuple(got))
+    texels = {tuple(up[y, x, :3].astype(np.float32) / np.float32(255.0)) for y in range(5) for x in range(7)}
+    assert (len(seen) > 2 * len(texels)) if sampler & 1 else (seen <= texels)     # linear blends, nearest returns texels
+    assert osc.sample_rgb(1, 0.5, 0.5).tolist() == [0.0, 0.0, 0.0]    # beyond the texture array: black
+    nanc = osc.sample_rgb(0, float("nan"), 0.3)                       # a NaN uv: defined (texel 0 / the -2^30 texel), never a fault
+    assert np.isfinite(nanc).all()
+
+
+def test_oracle_sampler_texel_values(oracle_mod, obj_loader):
+    """The oracle's sampler itself against the numpy restatement, bit for bit, through a probe scene: an EMISSIVE-free quad lit by a
+    constant sky, one sample, one bounce — pixel = texel(uv) * sky(scattered direction), so the ratio of two renders that differ only
+    in the sampler mode isolates the texel; here simply: renders with different modes differ, and mode 0 equals the default."""
+    rng = np.random.default_rng(12)
+    V, I, P, M, tex = _emissive_textured_quad(obj_loader, rng, -0.6, 1.7)
+    scene = obj_loader.Scene(V, I, P, M, textures=[tex])
+    u = oracle_mod.make_uniform(32, 32, (0.0, 0.0, -1.2), np.pi / 2, 0.0, max_bounces=1, samples=2)
+    base = oracle_mod.OracleScene(scene).render(u, mode=0)[0]
+    imgs = []
+    for sampler in range(4):
+        osc = oracle_mod.OracleScene(scene)
+        osc.set_sampler(sampler)
+        imgs.append(osc.render(u, mode=0)[0])
+    assert np.array_equal(imgs[0].view(np.uint32), base.view(np.uint32))
+    for a in range(4):
+        for b in range(a + 1, 4):
+            assert not np.array_equal(imgs[a], imgs[b]), (a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", [1, 2, 3])
+def test_sampler_modes_match_oracle(rt, oracle_mod, obj_loader, textured_scene, sampler):
+    """RT_OPT_SAMPLER 1..3 (linear / repeat / both) on the textured scene (uvs run from -0.25 to 1.25 on the wall) and on a quad whose
+    uvs run far outside [0, 1]: HIP == oracle bit for bit, and the option takes effect at the next dispatch."""
+    path, _ = textured_scene
+    s = obj_loader.load(path)
+    w, h = 96, 64
+    args = dict(pitch=-0.45, max_bounces=5, samples=4)
+    osc = oracle_mod.OracleScene(s)
+    osc.set_sampler(sampler)
+    want, _, cnt = osc.render(oracle_mod.make_uniform(w, h, (0.3, 2.2, -2.8), 1.45, **args), mode=0)
+    default, _, _ = oracle_mod.OracleScene(s).render(oracle_mod.make_uniform(w, h, (0.3, 2.2, -2.8), 1.45, **args), mode=0)
+    assert not np.array_equal(want, default)
+    with rt.Context(0) as ctx:
+        ctx.scene_finish(rt.HostScene(path))
+        ctx.accum_resize(w, h)
+        ctx.dispatch(rt.make_uniform(w, h, (0.3, 2.2, -2.8), 1.45, **args))
+        assert_images_identical(ctx.accum_download(), default, "default sampler")
+        ctx.set_option(rt.RT_OPT_SAMPLER, sampler)
+        ctx.accum_resize(w, h)
+        ctx.stats_reset()
+        ctx.dispatch(rt.make_uniform(w, h, (0.3, 2.2, -2.8), 1.45, **args))
+        assert ctx.stats().rays == cnt.rays
+        assert_images_identical(ctx.accum_download(), want, f"sampler {sampler}")
+        with pytest.raises(rt.RtError):
+            ctx.set_option(rt.RT_OPT_SAMPLER, 4)
+    rng = np.random.default_rng(13)
+    V, I, P, M, tex = _emissive_textured_quad(obj_loader, rng, -3.4, 5.2)
+    scene = obj_loader.Scene(V, I, P, M, textures=[tex])
+    osc = oracle_mod.OracleScene(scene)
+    osc.set_sampler(sampler)
+    u = dict(max_bounces=2, samples=3)
+    want, _, _ = osc.render(oracle_mod.make_uniform(80, 60, (0.2, 0.1, -1.5), np.pi / 2, 0.0, **u), mode=0)
+    with rt.Context(0) as ctx:
+        ctx.set_option(rt.RT_OPT_SAMPLER, sampler)
+        ctx.scene_upload(V, I, P, M)
+        ctx.textures_upload([tex])
+        ctx.accum_resize(80, 60)
+        ctx.dispatch(rt.make_uniform(80, 60, (0.2, 0.1, -1.5), np.pi / 2, 0.0, **u))
+        assert_images_identical(ctx.accum_download(), want, f"far uvs, sampler {sampler}")
