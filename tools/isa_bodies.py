@@ -18,8 +18,8 @@ open("/tmp/isa/marked.hip", "w").write(src)
 subprocess.check_call(f"cp {ROOT}/ray-tracing_amd/csrc/rt_device.h {ROOT}/ray-tracing_amd/csrc/rt_math.h {ROOT}/ray-tracing_amd/csrc/rt_pack.h /tmp/isa/ && /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off -fno-fast-math --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize --cuda-device-only -DRT_TU_PHASED -mllvm -structurizecfg-skip-uniform-regions=1 {EXTRA} -S /tmp/isa/marked.hip -o /tmp/isa/marked.s 2>/dev/null", shell=True)
 s = open("/tmp/isa/marked.s").read()
 FMT = os.environ.get('ISA_FMT', '2')   # node format instance: 0 = 48-byte binary, 1 = 32-byte binary, 2 = 8-ary
-SPH = os.environ.get('ISA_SPH', '0')   # 1: the instance with spheres / textures
-m = re.search(r'(_ZN12_GLOBAL__N_116rt_render_phasedILb0ELb0ELb' + SPH + r'ELb1ELi' + FMT + r'ELb0EEEv12RenderParams:.*?\.end_amdhsa_kernel)', s, re.S)
+SPH = os.environ.get('ISA_SPH', '0')   # EXT of the instance: 0 triangles, 1 + spheres, 2 + textures
+m = re.search(r'(_ZN12_GLOBAL__N_116rt_render_phasedILb0ELb0ELi' + SPH + r'ELb1ELi' + FMT + r'ELb0EEEv12RenderParams:.*?\.end_amdhsa_kernel)', s, re.S)
 body = m.group(1).split('\n')
 marks = [(i, l.strip().split()[-1]) for i, l in enumerate(body) if 'MARK' in l]
 def count(a, b):
