@@ -427,7 +427,11 @@ void collapse8(const rt_host::Bvh2 &bvh, const rt_host::Aabb *prim_boxes, Repack
 
     // breadth-first until there is enough independent work, then depth-first per thread
     std::vector<Item> frontier{{0u, 0u, 0u}};
+#ifdef RT_COLLAPSE_THREADS      // developer builds: the node / primitive numbering the collapse would give on that many threads
+    const unsigned hw = RT_COLLAPSE_THREADS;
+#else
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+#endif
     const unsigned want = n_prims >= (1u << 18) ? hw * 16u : 0u;
     size_t head = 0;
     while (head < frontier.size() && frontier.size() - head < want) { const Item it = frontier[head++]; process(it, frontier); }
