@@ -287,6 +287,8 @@ def report(args, cfg, rt, ctx, world, dt, rays, kernel_ms, launches, stats, cus,
                     "valu": {"ceiling_mrays": valu, "frac": achieved_mrays / valu, "rate_vs_all_fma_stream": achieved_mrays / (valu * fma_peak / valu_peak),
                              "wave_insts_per_ray": oc["valu_wave_insts_per_ray"], "insts_per_simd_clk_peak": valu_peak, "insts_per_simd_clk_fma_peak": fma_peak,
                              "insts_per_simd_clk_in_profile": oc.get("measured_valu_insts_per_simd_clk"), "lane_utilization": oc.get("valu_lane_utilization")},
+                    "l2_read_GBps_in_profile": oc.get("l2_read_GBps"), "l2_hit_rate_in_profile": oc.get("l2_hit_rate"), "waves_per_simd_in_profile": oc.get("waves_per_simd"),
+                    "kernel_ms_in_profile": oc.get("kernel_ms_in_profile"),
                     "cus": cus, "clock_hz": clock_hz, "profile": oc.get("profile"), "kernel_source_sha256_of_profile": oc.get("kernel_source_sha256"),
                     "git_head_at_reduction": oc.get("git_head_at_reduction"), "stale": stale,
                     "note": "ceilings = units x nominal clock x calibrated peak rate of the counter (profiles/r3_calibration.txt: 1.50 TCP_TOTAL_CACHE_ACCESSES per clock per CU for "

@@ -118,6 +118,9 @@ if out and len(sys.argv) > 3:
                           "valu_lane_utilization": d["derived"]["valu_lane_utilization"],
                           "measured_l1_tag_lookups_per_clk_per_cu": d["derived"]["l1_tag_lookups_per_clk_per_cu"],
                           "measured_valu_insts_per_simd_clk": d["derived"]["valu_insts_per_simd_clk"],
+                          # what BASELINE.md asks to be reported beside the HBM fraction: L2 bandwidth, wave occupancy (VALU busy = the valu entry)
+                          "l2_read_GBps": d["derived"]["l2_read_GBps"], "l2_hit_rate": d["derived"]["l2_hit_rate"], "waves_per_simd": d["derived"]["waves_per_simd"],
+                          "kernel_ms_in_profile": avg_ms,
                           "method": "rocprofv3 --pmc SQ_INSTS_VALU / TCP_TOTAL_CACHE_ACCESSES_sum per launch divided by the launch's exact device-side ray count; "
                                     "peaks in the counters' own units from profiles/r3_calibration.txt (tools/microbench/calibrate.hip under the same --pmc passes): "
                                     "1.50 TCP_TOTAL_CACHE_ACCESSES per nominal clock per CU (fully divergent 16-byte lane-loads, L1 hits), "
