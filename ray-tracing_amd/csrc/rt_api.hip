@@ -1443,8 +1443,11 @@ int rt_dispatch_frames_static(rt_context *ctx, RtUniform *uniform, uint32_t n_fr
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(ctx->stream, &cap);
     const bool capturing = cap != hipStreamCaptureStatusNone;
+    // held from the wait on the previous user's event to the record of this call's: two host threads cannot both queue behind the
+    // same predecessor and then run side by side (launches are asynchronous, so the lock is held for microseconds)
+    std::unique_lock<std::mutex> lock(g_scratch_mutex, std::defer_lock);
     if (!capturing) {
-        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        lock.lock();
         if (g_scratch_used[ctx->device]) RT_HIP(hipStreamWaitEvent(ctx->stream, g_scratch_done[ctx->device], 0));
         RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     }
@@ -1458,13 +1461,16 @@ int rt_dispatch_frames_static(rt_context *ctx, RtUniform *uniform, uint32_t n_fr
         }
         uniform->frame += 1;                               // src/app.rs:96
         r = launch(ctx, *uniform, group, sc);
-        if (r) return r;
+        if (r) {
+            // whatever part of the run did reach the stream still uses the scratch: the next user must queue behind it
+            if (!capturing && hipEventRecord(g_scratch_done[ctx->device], ctx->stream) == hipSuccess) g_scratch_used[ctx->device] = true;
+            return r;
+        }
         uniform->accumulation_frame += group - 1;
         uniform->frame += group - 1;
         i += group;
     }
     if (!capturing) {
-        std::lock_guard<std::mutex> lock(g_scratch_mutex);
         RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
         RT_HIP(hipEventRecord(g_scratch_done[ctx->device], ctx->stream));
         g_scratch_used[ctx->device] = true;
