@@ -122,6 +122,34 @@ __global__ __launch_bounds__(256) void gather16(const float *__restrict__ table,
     if (acc == 123.456f) out[0] = acc;
 }
 
+// one random 64-byte record per lane per step, fetched whole (4 x 16 bytes of one line): the access pattern of an 8-ary node visit whose
+// records miss every cache (table far beyond L2 and the 256 MB Infinity Cache) -> what FETCH_SIZE counts per such record, and the rate the
+// memory system sustains for it
+__global__ __launch_bounds__(256) void gather_record64(const float *__restrict__ table, uint32_t mask_lines, int iters, float *out) {
+    uint32_t s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    float acc = 0.0f;
+    for (int i = 0; i < iters; i++) {
+        s = s * 747796405u + 2891336453u;
+        const float4 *r = reinterpret_cast<const float4 *>(table + (size_t)((s >> 5) & mask_lines) * 16u);
+        const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+        acc += (a.x + b.y) + (c.z + d.w);
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+// the same with 128-byte records (two adjacent 64-byte halves, 128-byte aligned): one fabric request per record would mean a request IS a 128-byte line
+__global__ __launch_bounds__(256) void gather_record128(const float *__restrict__ table, uint32_t mask_lines, int iters, float *out) {
+    uint32_t s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    float acc = 0.0f;
+    for (int i = 0; i < iters; i++) {
+        s = s * 747796405u + 2891336453u;
+        const float4 *r = reinterpret_cast<const float4 *>(table + (size_t)((s >> 5) & mask_lines & ~1u) * 16u);
+        const float4 a = r[0], b = r[3], c = r[4], d = r[7];
+        acc += (a.x + b.y) + (c.z + d.w);
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
 int main() {
     float *out;
     CHECK(hipMalloc((void **)&out, 4));
@@ -197,6 +225,36 @@ int main() {
         time_gather(1, gather16<1>);
         time_gather(4, gather16<4>);
         time_gather(64, gather16<64>);
+        CHECK(hipFree(d));
+    }
+    {   // 4 GB of 64-byte records, every fetch a miss all the way to HBM
+        const uint32_t lines = 1u << 26;
+        float *d;
+        CHECK(hipMalloc((void **)&d, (size_t)lines * 64));
+        CHECK(hipMemset(d, 0, (size_t)lines * 64));
+        const int rblocks = cus * 8, riters = 1000;
+        for (int rep = 0; rep < 2; rep++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(gather_record64, dim3(rblocks), dim3(256), 0, 0, d, lines - 1, riters, out);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double records = (double)rblocks * 256 * riters;
+            printf("%d | random 64-byte records from a 4 GB table (4 x 16 B of one line per lane), rep %d | records %.0f | %.4f ms | %.1f GB/s of records (64 B each), %.1f GB/s if every miss fills a 128-byte line\n",
+                   dispatch++, rep, records, ms, records * 64 / (ms * 1e-3) / 1e9, records * 128 / (ms * 1e-3) / 1e9);
+        }
+        for (int rep = 0; rep < 2; rep++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(gather_record128, dim3(rblocks), dim3(256), 0, 0, d, lines - 1, riters, out);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double records = (double)rblocks * 256 * riters;
+            printf("%d | random 128-byte records from a 4 GB table (both 64-byte halves touched), rep %d | records %.0f | %.4f ms | %.1f GB/s of records (128 B each)\n",
+                   dispatch++, rep, records, ms, records * 128 / (ms * 1e-3) / 1e9);
+        }
         CHECK(hipFree(d));
     }
     return 0;
