@@ -460,8 +460,14 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     cdev = dev if backend == "nccl" else torch.device("cpu")     # where collective operands live
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1: a process group, barrier, reductions and the gather even for ONE rank — on a one-GPU box this is the only
+    # way the nccl (= RCCL) branch below ever executes (tests/test_gpu_parity.py::test_bench_rccl_path_with_one_rank)
+    force_dist = os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ and not os.environ.get("RT_BENCH_INIT_FILE"):
+            import tempfile
+            os.environ["RT_BENCH_INIT_FILE"] = os.path.join(tempfile.mkdtemp(prefix="rt_bench_rdv_"), "store")
         kw = {}
         if os.environ.get("RT_BENCH_INIT_FILE"):          # started by self_launch: file store
             kw = dict(init_method="file://" + os.environ["RT_BENCH_INIT_FILE"], rank=rank, world_size=world)
@@ -508,7 +514,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -520,7 +526,7 @@ def main():
         ctx.dispatch_frames(u, args.warmup)
     def gather():
         src = local if cdev.type == "cuda" else local.cpu()
-        return sharding.gather_framebuffer(src, W, H, rank, world)
+        return sharding.gather_framebuffer(src, W, H, rank, world, force_collective=force_dist)
 
     img = gather()
     del img
@@ -544,7 +550,7 @@ def main():
     t = torch.tensor([dt], dtype=torch.float64, device=cdev)
     r = torch.tensor([stats.rays, stats.pixel_frames], dtype=torch.int64, device=cdev)
     k = torch.tensor([kernel_ms], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
@@ -584,7 +590,7 @@ def main():
             raise SystemExit("verification failed: sharded image differs from the unsharded render")
 
     ctx.close()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -51,11 +51,12 @@ def deinterleave(stacked: torch.Tensor, width: int, height: int, world: int) -> 
     return t[:height].contiguous()
 
 
-def gather_framebuffer(local: torch.Tensor, width: int, height: int, rank: int, world: int, dst: int = 0):
+def gather_framebuffer(local: torch.Tensor, width: int, height: int, rank: int, world: int, dst: int = 0, force_collective: bool = False):
     """One collective: every rank's packed bands → rank `dst`.  Returns the
-    [height, width, 4] image on `dst`, None elsewhere."""
+    [height, width, 4] image on `dst`, None elsewhere.  force_collective: issue the gather even for one rank (a one-GPU box
+    then runs the RCCL path end to end: bench.py RT_BENCH_FORCE_DIST)."""
     assert local.numel() == local_buffer_floats(width, height, world)
-    if world == 1:
+    if world == 1 and not force_collective:
         return deinterleave(local.view(1, -1), width, height, 1)
     if rank == dst:
         out = torch.empty((world, local.numel()), dtype=local.dtype, device=local.device)

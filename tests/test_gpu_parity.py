@@ -958,3 +958,24 @@ def test_set_shard_after_accumulation_buffer(rt, ctxs):
         assert_images_identical(part, full[rows], "shard 1 of 2 after re-sharding")
     finally:
         ctx.set_shard(0, 1)
+
+
+@pytest.mark.skipif(os.environ.get("RT_AMD_NODE_FORMAT") is not None, reason="once is enough: not a node-format matter")
+def test_bench_rccl_path_with_one_rank():
+    """The nccl (= RCCL) branch of bench.py on the one GPU there is: RT_BENCH_FORCE_DIST=1 makes a one-rank run create the process group
+    (backend nccl, device_id), pass the barriers, reduce its timings and counters and issue the framebuffer gather as a collective, with the
+    render kernels and the collective ordered on one stream.  More than one rank needs more than one GPU; this is what can run here."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "RT_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu", "--verify", "--config", "C2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=110, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    metric = [l for l in lines if "metric" in l]
+    verify = [l for l in lines if "verify" in l]
+    assert len(metric) == 1 and metric[0]["n_gpus"] == 1 and metric[0]["value"] > 0
+    assert len(verify) == 1 and verify[0]["identical"] is True
