@@ -262,11 +262,11 @@ def report(args, cfg, rt, ctx, world, dt, rays, kernel_ms, launches, stats, cus,
                            "provenance": {"kernel_source_sha256": stamp,
                                           "traffic_profile": None if not traffic_rec else {k: traffic_rec.get(k) for k in ("profile", "kernel_source_sha256", "git_head_at_reduction", "frames_per_launch")},
                                           "stale": traffic_stale},
-                           "algorithmic": {"bytes_per_launch": algo_bytes, "achieved": algo_gbs, "frac": algo_gbs / HBM_PEAK_GBS,
+                           "algorithmic": {"bytes_per_launch": algo_bytes, "achieved": algo_gbs, "ratio_to_hbm_peak": algo_gbs / HBM_PEAK_GBS,
                                            "bytes_per_ray": bytes_per_ray, "nodes_per_ray": model["nodes_per_ray"],
                                            "tris_per_ray": model["tris_per_ray"], "hit_fraction": model["hit_fraction"], "byte_model": model_src,
                                            "note": "SURVEY section 8(d) model: 32 B per box test, 36 B per triangle test, 284 B per hit, 32 B per pixel-frame; "
-                                                   "above 1 means the records are cache-resident and these bytes never reach HBM"}}
+                                                   "a ratio above 1 (it is a ratio, not a utilisation) means the records are cache-resident and these bytes never reach HBM"}}
         # The on-chip ceilings (profiles/onchip.json, reduced from the PMC passes of the same command by tools/pmc_summary.py), each in
         # its counter's own unit against a peak calibrated with known instruction / lane-load counts (profiles/r3_calibration.txt):
         #   L1 path:  CUs x clock x 1.50 TCP_TOTAL_CACHE_ACCESSES per nominal clock per CU / the kernel's accesses per ray
