@@ -57,6 +57,9 @@ __shared__ float4 g_lds_materials[RT_LDS_MATERIALS * 4u];   // LDSM instances of
 #ifndef RT_NODE_EARLY_OUT
 #define RT_NODE_EARLY_OUT 2                  // leave the unrolled node steps when under 1/2 of the entering lanes remain (-1 %)
 #endif
+#ifndef RT_NODE_EARLY_OUT_WIDE
+#define RT_NODE_EARLY_OUT_WIDE 3             // 8-ary nodes: under 1/3 (a step is 230 instructions; C4 76.4 -> 75.3 ms per step against 1/2, 77.7 with no early return; C3 on binary nodes: 15.2 either way, 16.1 with none)
+#endif
 #ifndef RT_GUIDED_GRAIN
 #define RT_GUIDED_GRAIN 4u                     // chunks per claim while plenty of work is left
 #endif
@@ -960,8 +963,8 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
                 const int node_lanes = __popcll(__ballot(phase == PH_NODE));
 #pragma unroll
                 for (int rep = 0; rep < RT_NODE_REPS; rep++) {
-                // back to the scheduler early once fewer than 1/RT_NODE_EARLY_OUT of the lanes that came in are still on nodes
-                if (rep > 0 && __popcll(__ballot(phase == PH_NODE)) * RT_NODE_EARLY_OUT < node_lanes) break;
+                // back to the scheduler early once fewer than 1/RT_NODE_EARLY_OUT(_WIDE) of the lanes that came in are still on nodes
+                if (rep > 0 && __popcll(__ballot(phase == PH_NODE)) * (WIDE ? RT_NODE_EARLY_OUT_WIDE : RT_NODE_EARLY_OUT) < node_lanes) break;
                 if (kGuard && !WIDE && phase == PH_NODE &&
                     ((uint32_t)cur + (Q8 ? 2u : 3u) > P.n_node_chunks || ++guard_steps > kGuardMaxSteps)) { tl.guard++; phase = PH_SHADE; }
                 if (WIDE) {
