@@ -60,6 +60,9 @@ __shared__ float4 g_lds_materials[RT_LDS_MATERIALS * 4u];   // LDSM instances of
 #ifndef RT_NODE_EARLY_OUT_WIDE
 #define RT_NODE_EARLY_OUT_WIDE 3             // 8-ary nodes: under 1/3 (a step is 230 instructions; C4 76.4 -> 75.3 ms per step against 1/2, 77.7 with no early return; C3 on binary nodes: 15.2 either way, 16.1 with none)
 #endif
+#ifndef RT_STAGE_LINES
+#define RT_STAGE_LINES 0                     // per-wave LDS slots that collect the four 16-byte sums of a 64-byte line of the staging planes (0 = every sum is stored by itself)
+#endif
 #ifndef RT_GUIDED_GRAIN
 #define RT_GUIDED_GRAIN 4u                     // chunks per claim while plenty of work is left
 #endif
@@ -862,6 +865,14 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
     constexpr int kPrioNode = WIDE ? RT_PRIO_NODE_WIDE : RT_PRIO_NODE_BINARY, kPrioLeaf = WIDE ? RT_PRIO_LEAF_WIDE : RT_PRIO_LEAF_BINARY;
     extern __shared__ uint32_t lds_stack[];
     uint32_t *stack = lds_stack + threadIdx.x;
+#if RT_STAGE_LINES > 0
+    // multi-frame launches: a finished pixel-frame's sum (16 bytes) waits here for the other three of its 64-byte line of the staging
+    // planes and the line is stored whole; a slot that is needed for another line first gives up what it holds as single sums
+    __shared__ float4 s_lines[kBlock / 64][RT_STAGE_LINES][4];
+    __shared__ uint32_t s_line_tag[kBlock / 64][RT_STAGE_LINES];      // float4 index of the line / 4 + 1; 0 = free
+    __shared__ uint32_t s_line_mask[kBlock / 64][RT_STAGE_LINES];     // which of the four sums are there
+    if ((threadIdx.x & 63u) < (uint32_t)RT_STAGE_LINES) s_line_tag[threadIdx.x >> 6][threadIdx.x & 63u] = 0u;
+#endif
     if (WIDE) fill_next_slot_table();
     if (LDSM) {       // the host picks this instance when P.n_materials <= RT_LDS_MATERIALS
         if (threadIdx.x < P.n_materials * 4u) g_lds_materials[threadIdx.x] = reinterpret_cast<const float4 *>(P.materials)[threadIdx.x];
@@ -1167,6 +1178,46 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
         } else {
             // pixel boundary: write out finished pixel-frames (main.wgsl:27-32), then hand
             // pixel slots of the wave's chunk to the lanes
+#if RT_STAGE_LINES > 0
+            if (!RAYLIST && P.n_frames > 1u) {
+                const bool writer = phase == PH_FETCH && have_pixel;
+                unsigned long long m = __ballot(writer);
+                if (m) {
+                    // everything about the line is wave-uniform and stays in SGPRs; only the sum itself and the line on its way out use VGPRs
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                    do {
+                        uint32_t ln = lane;
+                        asm volatile("" : "+v"(ln));        // keeps what is derived from the lane number inside this loop (hoisted out of the kernel's main loop it costs the hot phases registers)
+                        const int l = __ffsll((long long)m) - 1;
+                        m &= m - 1ull;
+                        const uint32_t xf_l = (uint32_t)__builtin_amdgcn_readlane((int)S.xf, l), row_l = (uint32_t)__builtin_amdgcn_readlane((int)S.local_row, l);
+                        const uint32_t px = xf_l & 0xffffu;
+                        const uint32_t idx_l = (xf_l >> 16) * (uint32_t)P.stage_stride + row_l * P.width + px;      // < 2^32: the host keeps the work items below that
+                        // the 16 lines of an 8 x 8 tile go to 16 different slots (more slots: neighbouring tiles too)
+                        const uint32_t slot = (((row_l & 7u) << 1) | ((px >> 2) & 1u) | ((px >> 3) << 4)) & (uint32_t)(RT_STAGE_LINES - 1);
+                        const uint32_t g1 = (idx_l >> 2) + 1u;
+                        uint32_t tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_line_tag[w][slot]);
+                        uint32_t msk = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_line_mask[w][slot]);
+                        if (tag != g1) {
+                            // (a line leaves as 16 lanes x 4 bytes: one register of data per lane instead of four)
+                            if (tag != 0u) { if (ln < 16u && ((msk >> (ln >> 2)) & 1u)) (reinterpret_cast<float *>(P.stage) + (size_t)(tag - 1u) * 16u)[ln] = (&s_lines[w][slot][0].x)[ln]; }
+                            tag = g1; msk = 0u;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        if ((int)ln == l) { float *d = &s_lines[w][slot][idx_l & 3u].x; d[0] = S.total.x; d[1] = S.total.y; d[2] = S.total.z; d[3] = 0.0f; }
+                        msk |= 1u << (idx_l & 3u);
+                        __builtin_amdgcn_wave_barrier();
+                        if (msk == 0xFu) {
+                            if (ln < 16u) (reinterpret_cast<float *>(P.stage) + (size_t)(g1 - 1u) * 16u)[ln] = (&s_lines[w][slot][0].x)[ln];
+                            tag = 0u; msk = 0u;
+                        }
+                        if (ln == 0u) { s_line_tag[w][slot] = tag; s_line_mask[w][slot] = msk; }
+                        __builtin_amdgcn_wave_barrier();
+                    } while (m);
+                    if (writer) { tl.pixel_frames++; have_pixel = false; }
+                }
+            } else
+#endif
             if (phase == PH_FETCH && have_pixel) {
                 finish_pixel(P, S);
                 tl.pixel_frames++;
@@ -1241,6 +1292,14 @@ __global__ __launch_bounds__(kBlock, FMT >= 2 ? RT_PHASED_WAVES_WIDE : RT_PHASED
     if (lane == 0 && P.probe) {
         unsigned long long *pr = P.probe + 3u * (blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6));
         pr[0] = t_start; pr[1] = t_drain; pr[2] = wall_clock64();
+    }
+#endif
+#if RT_STAGE_LINES > 0
+    if (!RAYLIST && P.n_frames > 1u && lane < (uint32_t)RT_STAGE_LINES) {        // what the slots still hold
+        const uint32_t w = threadIdx.x >> 6, tag = s_line_tag[w][lane], msk = s_line_mask[w][lane];
+        if (tag != 0u)
+            for (uint32_t e = 0; e < 4u; e++)
+                if ((msk >> e) & 1u) P.stage[(size_t)(tag - 1u) * 4u + e] = s_lines[w][lane][e];
     }
 #endif
     if (!RAYLIST || COUNT) flush_tally<COUNT>(P, tl);
