@@ -86,7 +86,7 @@ except OSError:
 if rays and gui:
     d["per_ray"] = {"rays_per_launch": rays,
                     "valu_wave_insts_per_ray": vals['SQ_INSTS_VALU'] / rays,
-                    "valu_lane_insts_per_ray": vals['SQ_THREAD_CYCLES_VALU'] / 4 / rays if 'SQ_THREAD_CYCLES_VALU' in vals else None,
+                    "valu_lane_insts_per_ray": vals['SQ_THREAD_CYCLES_VALU'] / rays if 'SQ_THREAD_CYCLES_VALU' in vals else None,
                     "l1_tag_lookups_per_ray": vals['TCP_TOTAL_CACHE_ACCESSES_sum'] / rays,
                     "vmem_wave_loads_per_ray": vals['SQ_INSTS_VMEM_RD'] / rays,
                     "l2_requests_per_ray": vals['TCP_TCC_READ_REQ_sum'] / rays,
