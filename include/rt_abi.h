@@ -273,6 +273,17 @@ int rt_accum_bind(rt_context *ctx, void *device_ptr, uint64_t bytes, uint32_t w,
 /* ≙ uniform_buffer.upload + compute_pipeline.dispatch(ceil(W/8), ceil(H/8), 1),
  * src/app.rs:95-101.  uniform->window must equal the accumulation size. */
 int rt_dispatch(rt_context *ctx, const RtUniform *uniform);
+/* One frame in pieces, for interactive hosts: the reference's open item "Execute compute shader in chunks when in
+ * interactive mode" (TODO.md:9; no code in the reference yet — its one dispatch per frame, src/app.rs:100-101, holds the
+ * queue for the whole frame, which on a scene of C5's size is a third of a second).  Renders bands [band_begin, band_end)
+ * of the context's image — a band is 8 rows, the workgroup rows of shaders/main.wgsl:15; with rt_set_shard the context's
+ * OWN bands, numbered from 0 — exactly as rt_dispatch would: pixels are independent (main.wgsl:31-32), so the pieces of a
+ * frame, in any order, each band once, leave the bits of one rt_dispatch with the same uniform.  band_end beyond the last
+ * band means "to the end"; an empty range (also one that starts beyond the last band) renders nothing, band_begin > band_end is
+ * RT_ERR_INVALID_ARGUMENT.  The caller keeps the frame bookkeeping (as with rt_dispatch)
+ * and does what it likes between pieces (the calls only queue work on the context's stream; rt_sync waits); RtStats.dispatches counts the piece that ends at the last
+ * band.  Kernel variants 2 (default) and 0 only: variant 1 has no work queue to start part-way. */
+int rt_dispatch_bands(rt_context *ctx, const RtUniform *uniform, uint32_t band_begin, uint32_t band_end);
 /* n_frames consecutive dispatches; before each one `frame` is bumped and
  * `accumulation_frame` follows the cold-start sequence of src/app.rs:78-96
  * (first dispatch after a resize sees accumulation_frame = 0).  On return

@@ -960,11 +960,17 @@ int make_params(rt_context *ctx, const RtUniform &u, uint32_t n_frames, unsigned
 // which kernel instance a scene needs: 0 = triangles, untextured; 1 = + sphere records; 2 = + textures
 int kernel_ext(const rt_context *ctx) { return ctx->n_textures > 0 ? 2 : (ctx->hs->spheres.empty() ? 0 : 1); }
 
-int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned char *static_scratch = nullptr) {
+// band_begin / band_end: rt_dispatch_bands — only the work items of those local bands (one frame, queue-fed kernels)
+int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned char *static_scratch = nullptr, uint32_t band_begin = 0,
+           uint32_t band_end = 0xFFFFFFFFu) {
     RenderParams P;
     { int r = make_params(ctx, u, n_frames, static_scratch, P); if (r) return r; }
+    const bool last_piece = band_end >= P.local_bands;
+    if (band_end < P.local_bands) P.local_bands = band_end;     // the queue is band-major: the kernel sees an image that ends there ...
     if (ctx->opt_kernel != 1) {
-        RT_HIP(hipMemsetAsync(P.queue, 0, sizeof(DevQueue), ctx->stream));     // the head must start at zero, whatever the last call left
+        // ... and a queue whose head starts at the first slot of band_begin (zero for a whole frame), whatever the last call left
+        RT_HIP(hipMemsetAsync(P.queue, 0, sizeof(DevQueue), ctx->stream));
+        if (band_begin) RT_HIP(hipMemsetD32Async((hipDeviceptr_t)&P.queue->head, (int)(band_begin * P.tiles_x * 64u), 1, ctx->stream));
         const int ext = kernel_ext(ctx);
         const bool ldsm = P.n_materials <= RT_LDS_MATERIALS;
         const int sel = (ctx->node_compact ? 64 : 0) | (ctx->node_wide ? 32 : 0) | (ctx->node_q8 ? 16 : 0) | (ldsm ? 8 : 0) | (ctx->opt_count ? 4 : 0) | (ctx->opt_aov ? 2 : 0) | (ext << 8);
@@ -1013,7 +1019,7 @@ int launch(rt_context *ctx, const RtUniform &u, uint32_t n_frames = 1, unsigned 
         }
     }
 #endif
-    ctx->dispatches += n_frames;
+    if (last_piece) ctx->dispatches += n_frames;
     ctx->launches++;
     return RT_OK;
 }
@@ -1378,6 +1384,24 @@ int rt_dispatch(rt_context *ctx, const RtUniform *uniform) {
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
     ctx->accum_fresh = false;
+    return RT_OK;
+}
+
+int rt_dispatch_bands(rt_context *ctx, const RtUniform *uniform, uint32_t band_begin, uint32_t band_end) {
+    int r = check_dispatch(ctx, uniform);
+    if (r) return r;
+    if (ctx->opt_kernel == 1) return fail(RT_ERR_INVALID_ARGUMENT, "rt_dispatch_bands needs a queue-fed kernel (RT_OPT_KERNEL 2 or 0)");
+    if (band_begin > band_end) return fail(RT_ERR_INVALID_ARGUMENT, "rt_dispatch_bands: band range [%u, %u) of %u bands", band_begin, band_end, ctx->local_bands);
+    if (band_end > ctx->local_bands) band_end = ctx->local_bands;       // "to the end"; a range that starts beyond it is empty
+    if (band_begin > band_end) band_begin = band_end;
+    RT_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    if (band_begin < band_end) {
+        r = launch(ctx, *uniform, 1, nullptr, band_begin, band_end);
+        if (r) return r;
+        ctx->accum_fresh = false;
+    }
+    RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
     return RT_OK;
 }
 

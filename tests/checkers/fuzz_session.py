@@ -172,7 +172,15 @@ for session in range(args.sessions):
                     osc = oracle.OracleScene(scene, transforms=T, spheres=sc["S"], build_bvh=False)
                 if op == "dispatch":
                     frame, acc = int(rng.integers(1, 2**32)), int(rng.integers(0, 6))
-                    ctx.dispatch(uniform(rt, w, h, cam, frame, acc))
+                    if shards == 1 and opt["kernel"] != 1 and rng.random() < 0.4:     # the frame in pieces (rt_dispatch_bands), in random order
+                        nb = (h + 7) // 8
+                        cut = sorted(set([0, nb] + [int(c) for c in rng.integers(0, nb + 1, int(rng.integers(0, 4)))]))
+                        pieces = list(zip(cut[:-1], cut[1:]))
+                        for k in rng.permutation(len(pieces)):
+                            ctx.dispatch_bands(uniform(rt, w, h, cam, frame, acc), pieces[k][0], pieces[k][1] if pieces[k][1] < nb or rng.random() < 0.5 else 0xFFFFFFFF)
+                        log.append(f"pieces {pieces}")
+                    else:
+                        ctx.dispatch(uniform(rt, w, h, cam, frame, acc))
                     _, _, cnt = osc.render(uniform(oracle, w, h, cam, frame, acc), accum, mode=0)
                     rays_expected += int(cnt.rays)
                     fresh = False

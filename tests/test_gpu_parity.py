@@ -556,6 +556,61 @@ def test_multi_frame_launch_equals_frame_by_frame(rt, oracle_mod, oracle_scenes,
         assert_images_identical(a, want, "pipelined vs oracle")
 
 
+@pytest.mark.parametrize("world,w,h,kernel,cuts", [(1, 96, 54, 2, (0, 1, 4, 6)), (1, 61, 37, 0, (0, 3, 4)), (3, 61, 83, 2, (0, 1, 2)), (1, 8, 8, 2, (0,))])
+def test_frame_in_pieces_equals_one_dispatch(rt, oracle_mod, oracle_scenes, world, w, h, kernel, cuts):
+    """rt_dispatch_bands (the reference's open item TODO.md:9, "Execute compute shader in chunks when in interactive mode"): a frame
+    rendered as pieces of 8-row bands — in reverse order, with an empty piece, the last one open-ended, twice in a row (the second
+    frame accumulates onto the first, main.wgsl:30-32) — holds the bits and the ray count of rt_dispatch; also on a shard (its own
+    bands, numbered from 0) and with the queue-fed baseline kernel.  Kernel variant 1 has no queue: refused."""
+    cfg = config("C3")
+    rank = world - 1
+    def run(pieces):
+        ctx = rt.Context(0)
+        ctx.set_option(rt.RT_OPT_KERNEL, kernel)
+        ctx.scene_finish(rt.HostScene(scene_path("teapot-circle")))
+        ctx.set_shard(rank, world)
+        ctx.accum_resize(w, h)
+        launches = 0
+        for f in (0, 1):
+            u = uniforms_for(rt, cfg, w, h, samples=2)
+            u["frame"], u["accumulation_frame"] = 11 + f, f
+            if not pieces:
+                ctx.dispatch(u)
+                launches += 1
+                continue
+            ends = list(cuts[1:]) + [0xFFFFFFFF]
+            for b0, b1 in reversed(list(zip(cuts, ends))):
+                ctx.dispatch_bands(u, b0, b1)
+                launches += 1
+            ctx.dispatch_bands(u, cuts[-1], cuts[-1])            # empty: nothing is rendered, nothing is launched
+            ctx.dispatch_bands(u, 1000, 2000)                    # beyond the last band: empty too
+        st = ctx.stats()
+        img = ctx.accum_download()
+        if pieces:
+            with pytest.raises(rt.RtError):
+                ctx.dispatch_bands(u, 2, 1)
+            ctx.set_option(rt.RT_OPT_KERNEL, 1)
+            with pytest.raises(rt.RtError):
+                ctx.dispatch_bands(u, 0, 1)
+        ctx.close()
+        return img, st, launches
+    a, st_a, n_a = run(True)
+    b, st_b, n_b = run(False)
+    assert st_a.rays == st_b.rays and st_a.pixel_frames == st_b.pixel_frames
+    assert st_a.dispatches == st_b.dispatches == 2 and st_a.launches == n_a and st_b.launches == n_b == 2
+    assert_images_identical(a, b, "frame in pieces vs one dispatch")
+    if world == 1:
+        acc = np.zeros((h, w, 4), np.float32)
+        rays = 0
+        for f in (0, 1):
+            u = uniforms_for(oracle_mod, cfg, w, h, samples=2)
+            u["frame"], u["accumulation_frame"] = 11 + f, f
+            _, _, cnt = oracle_scenes("teapot-circle").render(u, acc, mode=1)
+            rays += int(cnt.rays)
+        assert st_a.rays == rays
+        assert_images_identical(a, acc, "frame in pieces vs oracle")
+
+
 def _soup(obj_loader, rng, n, centre, spread, size):
     """n random triangles around `centre`: corners within `size` of a point drawn within `spread`."""
     c = centre + (rng.random((n, 1, 3)) - 0.5) * 2 * spread
