@@ -282,7 +282,7 @@ int rt_dispatch(rt_context *ctx, const RtUniform *uniform);
  * band means "to the end"; an empty range (also one that starts beyond the last band) renders nothing, band_begin > band_end is
  * RT_ERR_INVALID_ARGUMENT.  The caller keeps the frame bookkeeping (as with rt_dispatch)
  * and does what it likes between pieces (the calls only queue work on the context's stream; rt_sync waits); RtStats.dispatches counts the piece that ends at the last
- * band.  Kernel variants 2 (default) and 0 only: variant 1 has no work queue to start part-way. */
+ * band; for rt_dispatch_frames' cold-start rule (first dispatch after a resize) any piece, even an empty one, is a dispatch.  Kernel variants 2 (default) and 0 only: variant 1 has no work queue to start part-way. */
 int rt_dispatch_bands(rt_context *ctx, const RtUniform *uniform, uint32_t band_begin, uint32_t band_end);
 /* n_frames consecutive dispatches; before each one `frame` is bumped and
  * `accumulation_frame` follows the cold-start sequence of src/app.rs:78-96
@@ -380,6 +380,9 @@ int rt_group_models_update(rt_group *g, const RtGpuModel *models, uint32_t n_mod
 int rt_group_accum_resize(rt_group *g, uint32_t w, uint32_t h);
 int rt_group_dispatch(rt_group *g, const RtUniform *uniform);
 int rt_group_dispatch_frames(rt_group *g, RtUniform *uniform, uint32_t n_frames);
+/* rt_dispatch_bands on every shard: each one renders ITS bands [band_begin, band_end) (numbered from 0 per shard: shard s of n holds image
+ * bands s, s + n, ...; a shard with fewer bands than band_begin renders nothing), so a frame in k pieces is k slices of every device's share. */
+int rt_group_dispatch_bands(rt_group *g, const RtUniform *uniform, uint32_t band_begin, uint32_t band_end);
 int rt_group_sync(rt_group *g);
 /* The same gather without the copy to the host: renders finished, bands gathered and de-interleaved on device_ids[0], and
  * *device_image = the w x h x 16-byte image THERE (owned by the group, valid until the next gather / resize / destroy).

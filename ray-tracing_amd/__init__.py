@@ -66,7 +66,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_set_option",
     "rt_scene_upload", "rt_spheres_upload", "rt_textures_upload", "rt_models_update",
     "rt_set_shard", "rt_accum_local_rows", "rt_accum_resize", "rt_accum_bind",
-    "rt_dispatch", "rt_dispatch_bands", "rt_dispatch_frames", "rt_dispatch_frames_static", "rt_frames_reserve", "rt_sync", "rt_capture_rgb8",
+    "rt_dispatch", "rt_dispatch_bands", "rt_group_dispatch_bands", "rt_dispatch_frames", "rt_dispatch_frames_static", "rt_frames_reserve", "rt_sync", "rt_capture_rgb8",
     "rt_accum_download", "rt_aov_download", "rt_stats", "rt_stats_reset", "rt_last_dispatch_ms",
     "rt_debug_alloc_count", "rt_group_peer_access", "rt_group_accum_gather",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_context", "rt_group_set_option", "rt_group_scene_upload",
@@ -169,6 +169,7 @@ def lib():
         L.rt_accum_bind.argtypes = [vp, vp, u64, u32, u32]
         L.rt_dispatch.argtypes = [vp, vp]
         L.rt_dispatch_bands.argtypes = [vp, vp, u32, u32]
+        L.rt_group_dispatch_bands.argtypes = [vp, vp, u32, u32]
         L.rt_dispatch_frames.argtypes = [vp, vp, u32]
         L.rt_dispatch_frames_static.argtypes = [vp, vp, u32]
         L.rt_frames_reserve.argtypes = [vp, u32]
@@ -532,6 +533,10 @@ class Group:
     def dispatch(self, uniform):
         u = np.ascontiguousarray(uniform)
         _check(lib().rt_group_dispatch(self.handle, u.ctypes.data))
+
+    def dispatch_bands(self, uniform, band_begin, band_end=0xFFFFFFFF):
+        u = np.ascontiguousarray(uniform)
+        _check(lib().rt_group_dispatch_bands(self.handle, u.ctypes.data, band_begin, band_end))
 
     def dispatch_frames(self, uniform, n_frames):
         assert uniform.flags.c_contiguous and uniform.dtype.itemsize == 80

@@ -1398,8 +1398,8 @@ int rt_dispatch_bands(rt_context *ctx, const RtUniform *uniform, uint32_t band_b
     if (band_begin < band_end) {
         r = launch(ctx, *uniform, 1, nullptr, band_begin, band_end);
         if (r) return r;
-        ctx->accum_fresh = false;
     }
+    ctx->accum_fresh = false;       // like rt_dispatch, whatever the range held (a shard of a group may own none of it): the cold start of src/app.rs:87-88 is over
     RT_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->timed = true;
     return RT_OK;
@@ -1846,6 +1846,12 @@ int rt_group_accum_resize(rt_group *g, uint32_t w, uint32_t h) {
 int rt_group_dispatch(rt_group *g, const RtUniform *uniform) {
     if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
     for (rt_context *c : g->ctx) { int r = rt_dispatch(c, uniform); if (r) return r; }
+    return RT_OK;
+}
+
+int rt_group_dispatch_bands(rt_group *g, const RtUniform *uniform, uint32_t band_begin, uint32_t band_end) {
+    if (!g) return fail(RT_ERR_INVALID_ARGUMENT, "group is null");
+    for (rt_context *c : g->ctx) { int r = rt_dispatch_bands(c, uniform, band_begin, band_end); if (r) return r; }   // each shard: its own bands of that range
     return RT_OK;
 }
 

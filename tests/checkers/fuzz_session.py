@@ -172,8 +172,8 @@ for session in range(args.sessions):
                     osc = oracle.OracleScene(scene, transforms=T, spheres=sc["S"], build_bvh=False)
                 if op == "dispatch":
                     frame, acc = int(rng.integers(1, 2**32)), int(rng.integers(0, 6))
-                    if shards == 1 and opt["kernel"] != 1 and rng.random() < 0.4:     # the frame in pieces (rt_dispatch_bands), in random order
-                        nb = (h + 7) // 8
+                    if opt["kernel"] != 1 and rng.random() < 0.4:     # the frame in pieces (rt_dispatch_bands; a group: every shard its own bands of the range), in random order
+                        nb = -(-((h + 7) // 8) // shards)
                         cut = sorted(set([0, nb] + [int(c) for c in rng.integers(0, nb + 1, int(rng.integers(0, 4)))]))
                         pieces = list(zip(cut[:-1], cut[1:]))
                         for k in rng.permutation(len(pieces)):

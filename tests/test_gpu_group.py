@@ -54,6 +54,36 @@ def test_group_equals_single_context(rt, scenes, n, w, h):
         assert_images_identical(small, one.accum_download(), f"group of {n}, second window")
 
 
+@pytest.mark.parametrize("n,w,h,cuts", [(3, 61, 83, (0, 2, 3)), (2, 40, 24, (0, 1))])
+def test_group_frame_in_pieces(rt, scenes, n, w, h, cuts):
+    """rt_group_dispatch_bands: every shard renders its own bands of the range; the pieces of a frame (any order, an open end,
+    a range beyond a short shard's last band) add up to one rt_dispatch of a single context, bit for bit."""
+    cfg = config("C3")
+    s = scenes("teapot-circle")
+    with rt.Context(0) as one:
+        one.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+        one.accum_resize(w, h)
+        for f in (0, 1):
+            u = _cold(rt, cfg, w, h, 2)
+            u["frame"], u["accumulation_frame"] = 21 + f, f
+            one.dispatch(u)
+        want, st1 = one.accum_download(), one.stats()
+    with rt.Group([0] * n) as g:
+        g.scene_upload(s.vertices, s.indices, s.primitives, s.models)
+        g.accum_resize(w, h)
+        for f in (0, 1):
+            u = _cold(rt, cfg, w, h, 2)
+            u["frame"], u["accumulation_frame"] = 21 + f, f
+            ends = list(cuts[1:]) + [0xFFFFFFFF]
+            for b0, b1 in reversed(list(zip(cuts, ends))):
+                g.dispatch_bands(u, b0, b1)
+        got, st = g.accum_download(), g.stats()
+        assert st.rays == st1.rays and st.pixel_frames == st1.pixel_frames == w * h * 2
+        assert_images_identical(got, want, "group frame in pieces vs one context")
+        with pytest.raises(rt.RtError):
+            g.dispatch_bands(u, 3, 2)
+
+
 @pytest.mark.parametrize("refit", [2, 0])
 def test_group_models_update_and_spheres(rt, oracle_mod, obj_loader, scenes, refit):
     """rt_group_models_update ≙ App::upload_models on every device (device refit, or one host rebuild shared by all), with
